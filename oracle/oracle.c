@@ -1,0 +1,1415 @@
+/*
+ * CPU ORACLE - TEST INFRASTRUCTURE ONLY.  See oracle.h.
+ *
+ * PARITY UNPINNED against the reference's own output (it has no tests or
+ * fixtures and cannot run offline); this file restates the GLSL literally.
+ *
+ * Pinned implementation choices (GLSL leaves these open):
+ *   - IEEE binary32 everywhere, round-to-nearest, no fused multiply-add
+ *     (build with -ffp-contract=off, never -ffast-math);
+ *   - dot(a,b)        = (a.x*b.x + a.y*b.y) + a.z*b.z
+ *   - mat*vec         = ((c0*x + c1*y) + c2*z) [+ c3*w]
+ *   - normalize(v)    = v * (1 / sqrt(dot(v,v)))
+ *   - inversesqrt(x)  = 1 / sqrt(x)
+ *   - inverse(mat3)   = adjugate * (1/det), det expanded along the first row
+ *   - mix(x,y,a)      = x*(1-a) + y*a
+ *   - max/min         = fmaxf/fminf (a NaN operand yields the other operand)
+ *   - constant expressions such as ONE_OVER_PI are folded in double precision
+ *     and then rounded to float, as glslang does
+ *   - texture()       = fp32 bilinear weights, texel centres at +0.5, REPEAT
+ *   - traversal stack and TLAS candidate list are large enough never to
+ *     overflow (the shader's are 63 and 15 entries and overflow silently);
+ *     rt_stats.max_stack reports the depth actually needed.
+ */
+#include "oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------- */
+/* shaders/common/utils.glsl:1-9                                             */
+#define PI_D 3.1415926535
+#define PI ((float) PI_D)
+#define TWO_PI ((float) (2.0 * PI_D))
+#define ONE_OVER_PI ((float) (1.0 / PI_D))
+#define ONE_OVER_TWO_PI ((float) (1.0 / (2.0 * PI_D)))
+#define ONE_OVER_FOUR_PI ((float) (1.0 / (4.0 * PI_D)))
+#define RT_INFINITY ((float) (1.0 / 0.00000000000001))
+#define EPSILON 0.0001f
+
+#define STACK_CAPACITY 1024
+#define CANDIDATE_CAPACITY 65536
+
+typedef struct { float x, y, z; } v3;
+typedef struct { float x, y, z, w; } v4;
+typedef struct { v3 c0, c1, c2; } m3;
+
+static inline v3 V3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+static inline v3 splat(float s) { return V3(s, s, s); }
+static inline v3 add(v3 a, v3 b) { return V3(a.x + b.x, a.y + b.y, a.z + b.z); }
+static inline v3 sub(v3 a, v3 b) { return V3(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline v3 mulv(v3 a, v3 b) { return V3(a.x * b.x, a.y * b.y, a.z * b.z); }
+static inline v3 divv(v3 a, v3 b) { return V3(a.x / b.x, a.y / b.y, a.z / b.z); }
+static inline v3 scale(v3 a, float s) { return V3(a.x * s, a.y * s, a.z * s); }
+static inline v3 divs(v3 a, float s) { return V3(a.x / s, a.y / s, a.z / s); }
+static inline v3 neg(v3 a) { return V3(-a.x, -a.y, -a.z); }
+static inline float dot(v3 a, v3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+static inline v3 cross(v3 a, v3 b) {
+    return V3(a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y);
+}
+static inline float length(v3 a) { return sqrtf(dot(a, a)); }
+static inline v3 normalize(v3 a) { return scale(a, 1.0f / sqrtf(dot(a, a))); }
+static inline float comp(v3 a, int i) { return i == 0 ? a.x : (i == 1 ? a.y : a.z); }
+static inline float mixf(float x, float y, float a) { return x * (1.0f - a) + y * a; }
+static inline v3 mix3(v3 x, v3 y, float a) { return add(scale(x, 1.0f - a), scale(y, a)); }
+static inline float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+static inline float signf(float x) { return x > 0.0f ? 1.0f : (x < 0.0f ? -1.0f : 0.0f); }
+static inline v3 from3(const float* p) { return V3(p[0], p[1], p[2]); }
+
+/* mat4 (column-major) times (v, w). */
+static inline v3 mat4_mul_point(const rt_mat4* m, v3 v, float w) {
+    v3 r;
+    r.x = ((m->m[0][0] * v.x + m->m[1][0] * v.y) + m->m[2][0] * v.z) + m->m[3][0] * w;
+    r.y = ((m->m[0][1] * v.x + m->m[1][1] * v.y) + m->m[2][1] * v.z) + m->m[3][1] * w;
+    r.z = ((m->m[0][2] * v.x + m->m[1][2] * v.y) + m->m[2][2] * v.z) + m->m[3][2] * w;
+    return r;
+}
+static inline m3 mat3_of(const rt_mat4* m) {
+    m3 r;
+    r.c0 = V3(m->m[0][0], m->m[0][1], m->m[0][2]);
+    r.c1 = V3(m->m[1][0], m->m[1][1], m->m[1][2]);
+    r.c2 = V3(m->m[2][0], m->m[2][1], m->m[2][2]);
+    return r;
+}
+static inline m3 mat3_identity(void) {
+    m3 r = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}};
+    return r;
+}
+static inline v3 mat3_mul(m3 m, v3 v) {
+    return add(add(scale(m.c0, v.x), scale(m.c1, v.y)), scale(m.c2, v.z));
+}
+/* transpose(m) * v */
+static inline v3 mat3_tmul(m3 m, v3 v) { return V3(dot(m.c0, v), dot(m.c1, v), dot(m.c2, v)); }
+static m3 mat3_inverse(m3 m) {
+    float const a00 = m.c0.x, a01 = m.c0.y, a02 = m.c0.z;
+    float const a10 = m.c1.x, a11 = m.c1.y, a12 = m.c1.z;
+    float const a20 = m.c2.x, a21 = m.c2.y, a22 = m.c2.z;
+    float const det = (a00 * (a11 * a22 - a21 * a12) - a10 * (a01 * a22 - a21 * a02)) +
+                      a20 * (a01 * a12 - a11 * a02);
+    float const inv_det = 1.0f / det;
+    m3 r;
+    r.c0.x = (a11 * a22 - a21 * a12) * inv_det;
+    r.c1.x = -(a10 * a22 - a20 * a12) * inv_det;
+    r.c2.x = (a10 * a21 - a20 * a11) * inv_det;
+    r.c0.y = -(a01 * a22 - a21 * a02) * inv_det;
+    r.c1.y = (a00 * a22 - a20 * a02) * inv_det;
+    r.c2.y = -(a00 * a21 - a20 * a01) * inv_det;
+    r.c0.z = (a01 * a12 - a11 * a02) * inv_det;
+    r.c1.z = -(a00 * a12 - a10 * a02) * inv_det;
+    r.c2.z = (a00 * a11 - a10 * a01) * inv_det;
+    return r;
+}
+
+/* shaders/common/utils.glsl:11-17 */
+static inline float pad_above_zero(float val) {
+    return fabsf(val) < EPSILON ? signf(val) * EPSILON : val;
+}
+static inline float luminance(v3 c) { return (0.212671f * c.x + 0.715160f * c.y) + 0.072169f * c.z; }
+
+/* shaders/common/utils.glsl:62-66 */
+static inline void onb(v3 N, v3* T, v3* B) {
+    v3 const up = fabsf(N.z) < 0.9999999f ? V3(0, 0, 1) : V3(1, 0, 0);
+    *T = normalize(cross(up, N));
+    *B = cross(N, *T);
+}
+
+/* shaders/common/to_ldr.glsl:1-3 */
+static inline v3 tone_mapping(v3 c) { return divv(c, add(c, splat(1.0f))); }
+
+/* ------------------------------------------------------------------------- */
+/* shaders/common/random.glsl:4-24                                           */
+static inline uint32_t random_seed_step(uint32_t r) { return r * 747796405u + 1u; }
+static inline uint32_t hash_combine(uint32_t seed, uint32_t v) {
+    return v + 0x9e3779b9u + (seed << 6) + (seed >> 2);
+}
+static inline uint32_t rand_uint(uint32_t* seed, uint32_t lo, uint32_t hi) {
+    *seed = random_seed_step(*seed);
+    uint32_t const range = hi - lo + 1u;
+    return lo + *seed % range;
+}
+static inline float rand_01(uint32_t* seed) {
+    *seed = random_seed_step(*seed);
+    uint32_t word = ((*seed >> ((*seed >> 28) + 4u)) ^ *seed) * 277803737u;
+    word = (word >> 22) ^ word;
+    return (float) word / 4294967295.0f;
+}
+
+/* ------------------------------------------------------------------------- */
+typedef struct { v3 origin, direction; } ray_t;
+
+/* per-thread work counters */
+typedef struct {
+    uint64_t closest_rays, shadow_rays, nodes, tris, max_stack;
+} counters_t;
+
+typedef struct {
+    const rt_scene_desc* sc;
+    uint32_t max_depth;
+    uint32_t* seed;      /* the shader's global `seed` */
+    counters_t* cnt;
+    uint32_t* stack;     /* STACK_CAPACITY words */
+    uint32_t* candidates;/* CANDIDATE_CAPACITY words */
+} ctx_t;
+
+/* shaders/raytracer/ray.glsl:11-31 */
+static int hit_aabb(const rt_bvh_node* n, v3 origin, v3 inv_d, const int neg[3], float t_min,
+    float t_max) {
+    float const lo_hi[3][2] = {{n->x_min, n->x_max}, {n->y_min, n->y_max}, {n->z_min, n->z_max}};
+    for (int a = 0; a < 3; ++a) {
+        float const inv = comp(inv_d, a);
+        int const negative = neg[a];
+        float const orig = comp(origin, a);
+        float const t0 = (lo_hi[a][negative] - orig) * inv;
+        float const t1 = (lo_hi[a][1 - negative] - orig) * inv;
+        t_min = fmaxf(t0, t_min);
+        t_max = fminf(t1, t_max);
+        if (t_min > t_max) {
+            return 0;
+        }
+    }
+    return 1;
+}
+
+/* shaders/raytracer/ray.glsl:40-45 */
+static inline int max_component_index(v3 v) {
+    float const ax = fabsf(v.x), ay = fabsf(v.y), az = fabsf(v.z);
+    return ax > ay ? (ax > az ? 0 : 2) : (ay > az ? 1 : 2);
+}
+
+typedef struct { float b0, b1, b2, t; int hit; } hit_record_t;
+
+/* Shared body of hit_triangle (ray.glsl:119-183) and hit_triangle_quick (:47-105):
+ * the two differ only in whether barycentrics and t are produced. */
+static hit_record_t hit_triangle(v3 a, v3 b, v3 c, ray_t ray, float t_min, float t_max) {
+    hit_record_t miss = {0.0f, 0.0f, 0.0f, 0.0f, 0};
+    v3 const edge1 = sub(b, a);
+    v3 const edge2 = sub(c, a);
+    if (fabsf(length(cross(edge1, edge2))) < 1e-8f) {
+        return miss;
+    }
+    v3 at = sub(a, ray.origin);
+    v3 bt = sub(b, ray.origin);
+    v3 ct = sub(c, ray.origin);
+    int const kz = max_component_index(ray.direction);
+    int const kx = kz + 1 == 3 ? 0 : kz + 1;
+    int const ky = kx + 1 == 3 ? 0 : kx + 1;
+    v3 const d = V3(comp(ray.direction, kx), comp(ray.direction, ky), comp(ray.direction, kz));
+    at = V3(comp(at, kx), comp(at, ky), comp(at, kz));
+    bt = V3(comp(bt, kx), comp(bt, ky), comp(bt, kz));
+    ct = V3(comp(ct, kx), comp(ct, ky), comp(ct, kz));
+    float const sx = -d.x / d.z;
+    float const sy = -d.y / d.z;
+    float const sz = 1.0f / d.z;
+    at.x += sx * at.z;
+    at.y += sy * at.z;
+    bt.x += sx * bt.z;
+    bt.y += sy * bt.z;
+    ct.x += sx * ct.z;
+    ct.y += sy * ct.z;
+    float const e0 = bt.x * ct.y - bt.y * ct.x;
+    float const e1 = ct.x * at.y - ct.y * at.x;
+    float const e2 = at.x * bt.y - at.y * bt.x;
+    if ((e0 < 0 || e1 < 0 || e2 < 0) && (e0 > 0 || e1 > 0 || e2 > 0)) {
+        return miss;
+    }
+    float const det = e0 + e1 + e2;
+    if (det == 0) {
+        return miss;
+    }
+    at.z *= sz;
+    bt.z *= sz;
+    ct.z *= sz;
+    float const t_scaled = (e0 * at.z + e1 * bt.z) + e2 * ct.z;
+    if (det < 0 && (t_scaled >= t_min * det || t_scaled < t_max * det)) {
+        return miss;
+    } else if (det > 0 && (t_scaled <= t_min * det || t_scaled > t_max * det)) {
+        return miss;
+    }
+    float const inv_det = 1.0f / det;
+    hit_record_t rec;
+    rec.b0 = e0 * inv_det;
+    rec.b1 = e1 * inv_det;
+    rec.b2 = e2 * inv_det;
+    rec.t = t_scaled * inv_det;
+    rec.hit = 1;
+    return rec;
+}
+
+/* shaders/raytracer/state.glsl:1-35 */
+typedef struct {
+    v3 hit_position, hit_normal, hit_tangent, hit_bitangent;
+    float hit_u, hit_v, hit_t;
+    int inst_material, inst_medium, inst_light;
+    int front_face;
+} state_t;
+
+typedef struct {
+    v3 albedo, emission;
+    float metallic, spec_trans, eta, ior, subsurface, roughness, specular_tint, anisotropic;
+    float ax, ay, sheen, sheen_tint, clearcoat, clearcoat_gloss;
+} surface_info_t;
+
+typedef struct {
+    v3 intensity;
+    float pdf;
+    v3 wi;
+    int type;
+} light_sample_t;
+
+/* ------------------------------------------------------------------------- */
+/* texture(): bilinear, REPEAT, single mip (src/vulkan/vulkan_image.cpp:309-330) */
+static inline uint32_t wrap_repeat(int i, uint32_t size) {
+    int const s = (int) size;
+    int m = i % s;
+    if (m < 0) {
+        m += s;
+    }
+    return (uint32_t) m;
+}
+static inline v4 load_texel(const rt_texture* t, uint32_t x, uint32_t y) {
+    size_t const idx = ((size_t) y * t->width + x) * 4;
+    v4 r;
+    if (t->format == RT_TEX_F32X4) {
+        const float* p = (const float*) t->data + idx;
+        r.x = p[0]; r.y = p[1]; r.z = p[2]; r.w = p[3];
+    } else {
+        const uint8_t* p = (const uint8_t*) t->data + idx;
+        r.x = (float) p[0] / 255.0f;
+        r.y = (float) p[1] / 255.0f;
+        r.z = (float) p[2] / 255.0f;
+        r.w = (float) p[3] / 255.0f;
+    }
+    return r;
+}
+static v4 sample_texture(const rt_texture* t, float u, float v) {
+    float const x = u * (float) t->width - 0.5f;
+    float const y = v * (float) t->height - 0.5f;
+    float const fx = floorf(x);
+    float const fy = floorf(y);
+    float const a = x - fx;
+    float const b = y - fy;
+    uint32_t const x0 = wrap_repeat((int) fx, t->width);
+    uint32_t const x1 = wrap_repeat((int) fx + 1, t->width);
+    uint32_t const y0 = wrap_repeat((int) fy, t->height);
+    uint32_t const y1 = wrap_repeat((int) fy + 1, t->height);
+    v4 const t00 = load_texel(t, x0, y0);
+    v4 const t10 = load_texel(t, x1, y0);
+    v4 const t01 = load_texel(t, x0, y1);
+    v4 const t11 = load_texel(t, x1, y1);
+    v4 r;
+    r.x = mixf(mixf(t00.x, t10.x, a), mixf(t01.x, t11.x, a), b);
+    r.y = mixf(mixf(t00.y, t10.y, a), mixf(t01.y, t11.y, a), b);
+    r.z = mixf(mixf(t00.z, t10.z, a), mixf(t01.z, t11.z, a), b);
+    r.w = mixf(mixf(t00.w, t10.w, a), mixf(t01.w, t11.w, a), b);
+    return r;
+}
+static inline v3 texture_rgb(const ctx_t* c, int tex, float u, float v) {
+    v4 const s = sample_texture(&c->sc->textures[tex], u, v);
+    return V3(s.x, s.y, s.z);
+}
+
+/* ------------------------------------------------------------------------- */
+/* megakernel_raytracer.comp:126-182 */
+static void get_surface_info(const ctx_t* c, state_t* st, surface_info_t* si) {
+    memset(si, 0, sizeof(*si));
+    if (st->inst_light >= 0) {
+        const rt_light* light = &c->sc->lights[st->inst_light];
+        if (st->front_face || light->type == RT_LIGHT_AREA_DOUBLE_SIDED) {
+            si->emission = from3(light->intensity);
+            if (light->emission_tex >= 0) {
+                si->emission =
+                    mulv(si->emission, texture_rgb(c, light->emission_tex, st->hit_u, st->hit_v));
+            }
+        } else {
+            si->emission = splat(0.0f);
+        }
+    } else if (st->inst_material >= 0) {
+        const rt_material* m = &c->sc->materials[st->inst_material];
+        si->albedo = from3(m->albedo);
+        si->emission = from3(m->emission);
+        si->metallic = m->metallic;
+        si->spec_trans = m->spec_trans;
+        si->eta = st->front_face ? 1.0f / m->ior : m->ior;
+        si->ior = m->ior;
+        si->subsurface = m->subsurface;
+        si->roughness = m->roughness;
+        si->specular_tint = m->specular_tint;
+        si->anisotropic = m->anisotropic;
+        si->sheen = m->sheen;
+        si->sheen_tint = m->sheen_tint;
+        si->clearcoat = m->clearcoat;
+        si->clearcoat_gloss = m->clearcoat_gloss;
+        if (m->albedo_tex >= 0) {
+            si->albedo = mulv(si->albedo, texture_rgb(c, m->albedo_tex, st->hit_u, st->hit_v));
+        }
+        if (m->emission_tex >= 0) {
+            si->emission = mulv(si->emission, texture_rgb(c, m->emission_tex, st->hit_u, st->hit_v));
+        }
+        if (m->normal_tex >= 0) {
+            v3 const texel = texture_rgb(c, m->normal_tex, st->hit_u, st->hit_v);
+            v3 const n = normalize(sub(scale(texel, 2.0f), splat(1.0f)));
+            st->hit_normal = normalize(add(add(scale(st->hit_tangent, n.x),
+                                               scale(st->hit_bitangent, n.y)),
+                scale(st->hit_normal, n.z)));
+        }
+        if (m->metallic_roughness_tex >= 0) {
+            v4 const texel =
+                sample_texture(&c->sc->textures[m->metallic_roughness_tex], st->hit_u, st->hit_v);
+            /* swizzle .bg: metallic = blue, roughness = green^2 */
+            si->metallic = texel.z;
+            si->roughness = fmaxf(texel.y * texel.y, 0.001f);
+        }
+        float const aspect = sqrtf(1.0f - m->anisotropic * 0.9f);
+        si->ax = fmaxf(0.001f, m->roughness / aspect);
+        si->ay = fmaxf(0.001f, m->roughness * aspect);
+    }
+}
+
+/* ------------------------------------------------------------------------- */
+static inline void load_tri_positions(const rt_triangle* t, v3* a, v3* b, v3* c) {
+    *a = from3(t->a.position_texu);
+    *b = from3(t->b.position_texu);
+    *c = from3(t->c.position_texu);
+}
+
+static inline void note_stack(ctx_t* c, uint32_t top) {
+    if (top > c->cnt->max_stack) {
+        c->cnt->max_stack = top;
+    }
+}
+
+/* Phase 1 of closest_hit / any_hit (megakernel_raytracer.comp:191-222, 331-362):
+ * walk the whole TLAS against the interval [0, t_max] and list every instance
+ * of every leaf whose box is hit.  Returns the number of candidates. */
+static uint32_t collect_instances(ctx_t* c, ray_t ray, float t_max) {
+    const rt_bvh_node* tlas = c->sc->tlas;
+    uint32_t top = 0;
+    uint32_t count = 0;
+    v3 const inv_dir = divv(splat(1.0f), ray.direction);
+    int const neg_dir[3] = {ray.direction.x < 0.0f, ray.direction.y < 0.0f, ray.direction.z < 0.0f};
+    uint32_t current = 0;
+    for (;;) {
+        const rt_bvh_node* node = &tlas[current];
+        ++c->cnt->nodes;
+        if (hit_aabb(node, ray.origin, inv_dir, neg_dir, 0.0f, t_max)) {
+            if (node->obj_count > 0) {
+                for (uint32_t i = node->first_obj; i < node->first_obj + node->obj_count; ++i) {
+                    if (count >= CANDIDATE_CAPACITY) {
+                        abort();
+                    }
+                    c->candidates[count++] = i;
+                }
+                if (top == 0) {
+                    break;
+                }
+                current = c->stack[--top];
+            } else {
+                int const negative = neg_dir[node->split_axis] != 0;
+                uint32_t const cur = negative ? node->right : current + 1;
+                uint32_t const next = negative ? current + 1 : node->right;
+                current = cur;
+                if (top >= STACK_CAPACITY) {
+                    abort();
+                }
+                c->stack[top++] = next;
+                note_stack(c, top);
+            }
+        } else {
+            if (top == 0) {
+                break;
+            }
+            current = c->stack[--top];
+        }
+    }
+    return count;
+}
+
+static inline ray_t to_object_space(const ctx_t* c, const rt_instance* inst, ray_t ray) {
+    if (inst->transform >= 0) {
+        const rt_mat4* inv = &c->sc->inverse_transforms[inst->transform];
+        ray_t r;
+        r.origin = mat4_mul_point(inv, ray.origin, 1.0f);
+        r.direction = mat4_mul_point(inv, ray.direction, 0.0f);
+        return r;
+    }
+    /* mat4(1.0) * vec4 still goes through the products: x*1 + y*0 + z*0 + w*0 */
+    rt_mat4 identity;
+    memset(&identity, 0, sizeof(identity));
+    identity.m[0][0] = identity.m[1][1] = identity.m[2][2] = identity.m[3][3] = 1.0f;
+    ray_t r;
+    r.origin = mat4_mul_point(&identity, ray.origin, 1.0f);
+    r.direction = mat4_mul_point(&identity, ray.direction, 0.0f);
+    return r;
+}
+
+typedef struct {
+    uint32_t instance, triangle;
+    hit_record_t rec;
+    float t_max;
+} closest_t;
+
+/* megakernel_raytracer.comp:184-276: phases 1 and 2 of closest_hit. */
+static closest_t find_closest(ctx_t* c, ray_t ray) {
+    closest_t best;
+    best.instance = ORACLE_MISS;
+    best.triangle = ORACLE_MISS;
+    memset(&best.rec, 0, sizeof(best.rec));
+    float t_max = RT_INFINITY;
+    ++c->cnt->closest_rays;
+    uint32_t const candidate_count = collect_instances(c, ray, t_max);
+    const rt_bvh_node* blas = c->sc->blas;
+    for (uint32_t i = 0; i < candidate_count; ++i) {
+        const rt_instance* inst = &c->sc->instances[c->candidates[i]];
+        const rt_mesh* mesh = &c->sc->meshes[inst->mesh];
+        ray_t const tr = to_object_space(c, inst, ray);
+        v3 const inv_dir = divv(splat(1.0f), tr.direction);
+        int const neg_dir[3] = {tr.direction.x < 0.0f, tr.direction.y < 0.0f, tr.direction.z < 0.0f};
+        uint32_t current = mesh->bvh_start;
+        uint32_t top = 0;
+        for (;;) {
+            const rt_bvh_node* node = &blas[current];
+            ++c->cnt->nodes;
+            if (hit_aabb(node, tr.origin, inv_dir, neg_dir, 0.0f, t_max)) {
+                if (node->obj_count > 0) {
+                    for (uint32_t t = node->first_obj; t < node->first_obj + node->obj_count; ++t) {
+                        v3 a, b, cc;
+                        load_tri_positions(&c->sc->triangles[t], &a, &b, &cc);
+                        ++c->cnt->tris;
+                        hit_record_t const rec = hit_triangle(a, b, cc, tr, 0.0f, t_max);
+                        if (rec.hit) {
+                            t_max = rec.t;
+                            best.instance = c->candidates[i];
+                            best.triangle = t;
+                            best.rec = rec;
+                        }
+                    }
+                    if (top == 0) {
+                        break;
+                    }
+                    current = c->stack[--top];
+                } else {
+                    int const negative = neg_dir[node->split_axis] != 0;
+                    uint32_t const cur = negative ? node->right : current + 1;
+                    uint32_t const next = negative ? current + 1 : node->right;
+                    current = cur;
+                    if (top >= STACK_CAPACITY) {
+                        abort();
+                    }
+                    c->stack[top++] = next;
+                    note_stack(c, top);
+                }
+            } else {
+                if (top == 0) {
+                    break;
+                }
+                current = c->stack[--top];
+            }
+        }
+    }
+    best.t_max = t_max;
+    return best;
+}
+
+/* megakernel_raytracer.comp:184-323 */
+static int closest_hit(ctx_t* c, ray_t ray, state_t* st) {
+    closest_t const best = find_closest(c, ray);
+    if (best.t_max == RT_INFINITY) {
+        return 0;
+    }
+    const rt_instance* inst = &c->sc->instances[best.instance];
+    const rt_triangle* tri = &c->sc->triangles[best.triangle];
+    v3 const a = from3(tri->a.position_texu);
+    v3 const b = from3(tri->b.position_texu);
+    v3 const cc = from3(tri->c.position_texu);
+    v3 const an = from3(tri->a.normal_texv);
+    v3 const bn = from3(tri->b.normal_texv);
+    v3 const cn = from3(tri->c.normal_texv);
+    float const au = tri->a.position_texu[3], av = tri->a.normal_texv[3];
+    float const bu = tri->b.position_texu[3], bv = tri->b.normal_texv[3];
+    float const cu = tri->c.position_texu[3], cv = tri->c.normal_texv[3];
+    hit_record_t const rec = best.rec;
+    st->hit_position = add(ray.origin, scale(ray.direction, rec.t));
+    v3 const outward = add(add(scale(an, rec.b0), scale(bn, rec.b1)), scale(cn, rec.b2));
+    st->front_face = dot(ray.direction, outward) < 0.0f;
+    st->hit_normal = st->front_face ? outward : neg(outward);
+    v3 const dp1 = sub(b, a);
+    v3 const dp2 = sub(cc, a);
+    float const du1 = bu - au, dv1 = bv - av;
+    float const du2 = cu - au, dv2 = cv - av;
+    float const inv = 1.0f / (du1 * dv2 - du2 * dv1);
+    st->hit_tangent = scale(sub(scale(dp1, dv2), scale(dp2, dv1)), inv);
+    st->hit_bitangent = scale(add(scale(dp1, -du2), scale(dp2, du1)), inv);
+    if (inst->transform >= 0) {
+        m3 const m = mat3_of(&c->sc->transforms[inst->transform]);
+        st->hit_normal = normalize(mat3_tmul(mat3_inverse(m), st->hit_normal));
+        st->hit_tangent = normalize(mat3_mul(m, st->hit_tangent));
+        st->hit_bitangent = normalize(mat3_mul(m, st->hit_bitangent));
+    }
+    st->hit_u = (rec.b0 * au + rec.b1 * bu) + rec.b2 * cu;
+    st->hit_v = (rec.b0 * av + rec.b1 * bv) + rec.b2 * cv;
+    st->hit_t = rec.t;
+    st->inst_material = inst->material;
+    st->inst_medium = inst->medium;
+    st->inst_light = inst->light;
+    return 1;
+}
+
+/* megakernel_raytracer.comp:325-411 */
+static int any_hit(ctx_t* c, ray_t ray, float t_max) {
+    ++c->cnt->shadow_rays;
+    uint32_t const candidate_count = collect_instances(c, ray, t_max);
+    const rt_bvh_node* blas = c->sc->blas;
+    for (uint32_t i = 0; i < candidate_count; ++i) {
+        const rt_instance* inst = &c->sc->instances[c->candidates[i]];
+        const rt_mesh* mesh = &c->sc->meshes[inst->mesh];
+        ray_t const tr = to_object_space(c, inst, ray);
+        v3 const inv_dir = divv(splat(1.0f), tr.direction);
+        int const neg_dir[3] = {tr.direction.x < 0.0f, tr.direction.y < 0.0f, tr.direction.z < 0.0f};
+        uint32_t current = mesh->bvh_start;
+        uint32_t top = 0;
+        for (;;) {
+            const rt_bvh_node* node = &blas[current];
+            ++c->cnt->nodes;
+            if (hit_aabb(node, tr.origin, inv_dir, neg_dir, 0.0f, t_max)) {
+                if (node->obj_count > 0) {
+                    for (uint32_t t = node->first_obj; t < node->first_obj + node->obj_count; ++t) {
+                        v3 a, b, cc;
+                        load_tri_positions(&c->sc->triangles[t], &a, &b, &cc);
+                        ++c->cnt->tris;
+                        if (hit_triangle(a, b, cc, tr, 0.0f, t_max).hit) {
+                            return 1;
+                        }
+                    }
+                    if (top == 0) {
+                        break;
+                    }
+                    current = c->stack[--top];
+                } else {
+                    int const negative = neg_dir[node->split_axis] != 0;
+                    uint32_t const cur = negative ? node->right : current + 1;
+                    uint32_t const next = negative ? current + 1 : node->right;
+                    current = cur;
+                    if (top >= STACK_CAPACITY) {
+                        abort();
+                    }
+                    c->stack[top++] = next;
+                    note_stack(c, top);
+                }
+            } else {
+                if (top == 0) {
+                    break;
+                }
+                current = c->stack[--top];
+            }
+        }
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* shaders/raytracer/sampling.glsl */
+static inline float power_heuristic(float a, float b) {
+    float const a2 = a * a;
+    return a2 / (a2 + b * b);
+}
+/* :6-13 - phi is 2*r1, without pi, as in the shader */
+static v3 uniform_sample_sphere(uint32_t* seed) {
+    float const r0 = rand_01(seed);
+    float const r1 = rand_01(seed);
+    float const cos_theta = 1.0f - 2.0f * r0;
+    float const sin_theta = sqrtf(fmaxf(0.0f, 1.0f - cos_theta * cos_theta));
+    float const phi = 2.0f * r1;
+    return V3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+}
+static v3 uniform_sample_hemisphere(uint32_t* seed, v3 vec) {
+    v3 const r = uniform_sample_sphere(seed);
+    return dot(r, vec) < 0.0f ? neg(r) : r;
+}
+static v3 uniform_sample_triangle(uint32_t* seed) {
+    float const r0 = rand_01(seed);
+    float const r1 = rand_01(seed);
+    float b0 = 0.0f, b1 = 0.0f;
+    if (r0 < r1) {
+        b0 = 0.5f * r0;
+        b1 = r1 - b0;
+    } else {
+        b1 = 0.5f * r1;
+        b0 = r0 - b1;
+    }
+    return V3(b0, b1, (1.0f - b0) - b1);
+}
+static v3 cosine_sample_hemisphere(uint32_t* seed) {
+    float const r1 = rand_01(seed);
+    float const r2 = rand_01(seed);
+    float const r = sqrtf(r1);
+    float const phi = TWO_PI * r2;
+    float const x = r * cosf(phi);
+    float const y = r * sinf(phi);
+    float const z = sqrtf(fmaxf(0.0f, (1.0f - x * x) - y * y));
+    return V3(x, y, z);
+}
+static v3 sample_ggx_vndf(uint32_t* seed, v3 V, float ax, float ay) {
+    float const r1 = rand_01(seed);
+    float const r2 = rand_01(seed);
+    v3 const Vh = normalize(V3(ax * V.x, ay * V.y, V.z));
+    float const lensq = Vh.x * Vh.x + Vh.y * Vh.y;
+    v3 const T1 = lensq > 0.0f ? scale(V3(-Vh.y, Vh.x, 0.0f), 1.0f / sqrtf(lensq)) : V3(1, 0, 0);
+    v3 const T2 = cross(Vh, T1);
+    float const r = sqrtf(r1);
+    float const phi = (2.0f * PI) * r2;
+    float const t1 = r * cosf(phi);
+    float t2 = r * sinf(phi);
+    float const s = 0.5f * (1.0f + Vh.z);
+    t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
+    v3 const Nh = add(add(scale(T1, t1), scale(T2, t2)),
+        scale(Vh, sqrtf(fmaxf(0.0f, (1.0f - t1 * t1) - t2 * t2))));
+    return normalize(V3(ax * Nh.x, ay * Nh.y, fmaxf(0.0f, Nh.z)));
+}
+static v3 sample_gtr1(uint32_t* seed, float roughness) {
+    float const r1 = rand_01(seed);
+    float const r2 = rand_01(seed);
+    float const a = fmaxf(0.001f, roughness);
+    float const a2 = a * a;
+    float const phi = r1 * TWO_PI;
+    float const cos_theta = sqrtf((1.0f - powf(a2, 1.0f - r2)) / (1.0f - a2));
+    float const sin_theta = clampf(sqrtf(1.0f - (cos_theta * cos_theta)), 0.0f, 1.0f);
+    float const sin_phi = sinf(phi);
+    float const cos_phi = cosf(phi);
+    return V3(sin_theta * cos_phi, sin_theta * sin_phi, cos_theta);
+}
+
+/* ------------------------------------------------------------------------- */
+/* shaders/raytracer/disney.glsl */
+static inline v3 to_local(v3 X, v3 Y, v3 Z, v3 V) { return V3(dot(V, X), dot(V, Y), dot(V, Z)); }
+static inline v3 to_world(v3 X, v3 Y, v3 Z, v3 V) {
+    return add(add(scale(X, V.x), scale(Y, V.y)), scale(Z, V.z));
+}
+/* :15-25 */
+static void tint_colors(const surface_info_t* si, float* F0, v3* csheen, v3* cspec0) {
+    float const lum = luminance(si->albedo);
+    v3 const ctint = lum > 0.0f ? divs(si->albedo, lum) : splat(1.0f);
+    float f0 = (1.0f - si->eta) / (1.0f + si->eta);
+    f0 *= f0;
+    *F0 = f0;
+    *cspec0 = scale(mix3(splat(1.0f), ctint, si->specular_tint), f0);
+    *csheen = mix3(splat(1.0f), ctint, si->sheen_tint);
+}
+/* :27-31 */
+static inline float schlick_weight(float u) {
+    float const m = clampf(1.0f - u, 0.0f, 1.0f);
+    float const m2 = m * m;
+    return m2 * m2 * m;
+}
+/* :33-59 */
+static v4 eval_disney_diffuse(const surface_info_t* si, v3 csheen, v3 V, v3 L, v3 H) {
+    v4 contrib = {0, 0, 0, 0};
+    if (L.z <= 0.0f) {
+        return contrib;
+    }
+    float const L_H = dot(L, H);
+    float const Rr = 2.0f * si->roughness * L_H * L_H;
+    float const FL = schlick_weight(L.z);
+    float const FV = schlick_weight(V.z);
+    float const Fretro = Rr * ((FL + FV) + FL * FV * (Rr - 1.0f));
+    float const Fd = (1.0f - 0.5f * FL) * (1.0f - 0.5f * FV);
+    float const Fss90 = 0.5f * Rr;
+    float const Fss = mixf(1.0f, Fss90, FL) * mixf(1.0f, Fss90, FV);
+    float const ss = 1.25f * (Fss * (1.0f / (L.z + V.z) - 0.5f) + 0.5f);
+    float const FH = schlick_weight(L_H);
+    v3 const Fsheen = scale(csheen, FH * si->sheen);
+    float const k = mixf(Fd + Fretro, ss, si->subsurface);
+    v3 const f = add(scale(scale(si->albedo, ONE_OVER_PI), k), Fsheen);
+    contrib.x = f.x;
+    contrib.y = f.y;
+    contrib.z = f.z;
+    contrib.w = L.z * ONE_OVER_PI;
+    return contrib;
+}
+/* :61-71 */
+static float dielectric_fresnel(float cos_theta_i, float eta) {
+    float const sin_theta_t2 = eta * eta * (1.0f - cos_theta_i * cos_theta_i);
+    if (sin_theta_t2 > 1.0f) {
+        return 1.0f;
+    }
+    float const cos_theta_t = sqrtf(fmaxf(1.0f - sin_theta_t2, 0.0f));
+    float const rs = (eta * cos_theta_t - cos_theta_i) / (eta * cos_theta_t + cos_theta_i);
+    float const rp = (eta * cos_theta_i - cos_theta_t) / (eta * cos_theta_i + cos_theta_t);
+    return 0.5f * (rs * rs + rp * rp);
+}
+/* :73-82 */
+static inline float gtr2_aniso(float N_H, float H_X, float H_Y, float ax, float ay) {
+    float const a = H_X / ax;
+    float const b = H_Y / ay;
+    float const c = (a * a + b * b) + N_H * N_H;
+    return 1.0f / (PI * ax * ay * c * c);
+}
+/* :84-93 */
+static inline float smith_g_aniso(float N_V, float V_X, float V_Y, float ax, float ay) {
+    float const a = V_X * ax;
+    float const b = V_Y * ay;
+    float const c = N_V;
+    return (2.0f * N_V) / (N_V + sqrtf((a * a + b * b) + c * c));
+}
+/* :95-110 */
+static v4 eval_microfacet_reflection(const surface_info_t* si, v3 V, v3 L, v3 H, v3 F) {
+    v4 contrib = {0, 0, 0, 0};
+    if (L.z <= 0.0f) {
+        return contrib;
+    }
+    float const D = gtr2_aniso(H.z, H.x, H.y, si->ax, si->ay);
+    float const G1 = smith_g_aniso(fabsf(V.z), V.x, V.y, si->ax, si->ay);
+    float const G2 = G1 * smith_g_aniso(fabsf(L.z), L.x, L.y, si->ax, si->ay);
+    float const denom = 4.0f * L.z * V.z;
+    contrib.x = F.x * D * G2 / denom;
+    contrib.y = F.y * D * G2 / denom;
+    contrib.z = F.z * D * G2 / denom;
+    contrib.w = G1 * D / (4.0f * V.z);
+    return contrib;
+}
+/* :112-134 */
+static v4 eval_microfacet_refraction(const surface_info_t* si, v3 V, v3 L, v3 H, v3 F) {
+    v4 contrib = {0, 0, 0, 0};
+    if (L.z >= 0.0f) {
+        return contrib;
+    }
+    float const L_H = dot(L, H);
+    float const V_H = dot(V, H);
+    float const D = gtr2_aniso(H.z, H.x, H.y, si->ax, si->ay);
+    float const G1 = smith_g_aniso(fabsf(V.z), V.x, V.y, si->ax, si->ay);
+    float const G2 = G1 * smith_g_aniso(fabsf(L.z), L.x, L.y, si->ax, si->ay);
+    float const denom = L_H + V_H * si->eta;
+    float const denom2 = denom * denom;
+    float const eta2 = si->eta * si->eta;
+    float const jacobian = fabsf(L_H) / pad_above_zero(denom2);
+    float const tail = pad_above_zero(fabsf(L.z * V.z));
+    v3 const tint = V3(powf(si->albedo.x, 0.5f), powf(si->albedo.y, 0.5f), powf(si->albedo.z, 0.5f));
+    float const absVH = fabsf(V_H);
+    contrib.x = tint.x * (1.0f - F.x) * D * G2 * absVH * jacobian * eta2 / tail;
+    contrib.y = tint.y * (1.0f - F.y) * D * G2 * absVH * jacobian * eta2 / tail;
+    contrib.z = tint.z * (1.0f - F.z) * D * G2 * absVH * jacobian * eta2 / tail;
+    contrib.w = G1 * fmaxf(0.0f, V_H) * D * jacobian / pad_above_zero(V.z);
+    return contrib;
+}
+/* :136-143 */
+static inline float gtr1(float N_H, float a) {
+    if (a >= 1.0f) {
+        return ONE_OVER_PI;
+    }
+    float const a2 = a * a;
+    float const t = 1.0f + (a2 - 1.0f) * N_H * N_H;
+    return (a2 - 1.0f) / (PI * logf(a2) * t);
+}
+/* :145-150 */
+static inline float smith_g(float N_V, float alpha) {
+    float const a = alpha * alpha;
+    float const b = N_V * N_V;
+    return (2.0f * N_V) / (N_V + sqrtf((a + b) - a * b));
+}
+/* :152-168 */
+static v4 eval_clearcoat(const surface_info_t* si, v3 V, v3 L, v3 H) {
+    v4 contrib = {0, 0, 0, 0};
+    if (L.z <= 0.0f) {
+        return contrib;
+    }
+    float const V_H = dot(V, H);
+    float const F = mixf(0.04f, 1.0f, schlick_weight(V_H));
+    float const D = gtr1(H.z, si->clearcoat_gloss);
+    float const G = smith_g(L.z, 0.25f) * smith_g(V.z, 0.25f);
+    float const jacobian = 1.0f / (4.0f * V_H);
+    contrib.x = contrib.y = contrib.z = F * D * G;
+    contrib.w = D * H.z * jacobian;
+    return contrib;
+}
+
+typedef struct {
+    float dielectric_wt, metal_wt, glass_wt;
+    float diffuse_pr, dielectric_pr, metal_pr, glass_pr, clearcoat_pr;
+    float F0;
+    v3 csheen, cspec0;
+} lobes_t;
+
+/* The block shared by eval_disney (:183-201) and sample_disney (:259-277). */
+static lobes_t lobe_weights(const surface_info_t* si, float V_z) {
+    lobes_t l;
+    tint_colors(si, &l.F0, &l.csheen, &l.cspec0);
+    l.dielectric_wt = (1.0f - si->metallic) * (1.0f - si->spec_trans);
+    l.metal_wt = si->metallic;
+    l.glass_wt = (1.0f - si->metallic) * si->spec_trans;
+    float const schlick_wt = schlick_weight(V_z);
+    l.diffuse_pr = l.dielectric_wt * luminance(si->albedo);
+    l.dielectric_pr = l.dielectric_wt * luminance(mix3(l.cspec0, splat(1.0f), schlick_wt));
+    l.metal_pr = l.metal_wt * luminance(mix3(si->albedo, splat(1.0f), schlick_wt));
+    l.glass_pr = l.glass_wt;
+    l.clearcoat_pr = 0.25f * si->clearcoat;
+    float const one_pr_sum =
+        1.0f / ((((l.diffuse_pr + l.dielectric_pr) + l.metal_pr) + l.glass_pr) + l.clearcoat_pr);
+    l.diffuse_pr *= one_pr_sum;
+    l.dielectric_pr *= one_pr_sum;
+    l.metal_pr *= one_pr_sum;
+    l.glass_pr *= one_pr_sum;
+    l.clearcoat_pr *= one_pr_sum;
+    return l;
+}
+
+static inline void accumulate(v4* acc, v4 contrib, float f_weight, float pdf_weight) {
+    acc->x += f_weight * contrib.x;
+    acc->y += f_weight * contrib.y;
+    acc->z += f_weight * contrib.z;
+    acc->w += pdf_weight * contrib.w;
+}
+
+/* :170-248.  V_world is the incoming ray direction (pointing at the surface). */
+static v4 eval_disney(const state_t* st, const surface_info_t* si, v3 V_world, v3 L_world) {
+    v4 bsdf_pdf = {0, 0, 0, 0};
+    v3 T, B;
+    v3 const N = st->hit_normal;
+    onb(N, &T, &B);
+    v3 const V = to_local(T, B, N, neg(V_world));
+    v3 const L = to_local(T, B, N, L_world);
+    v3 H = L.z > 0.0f ? normalize(add(L, V)) : normalize(add(L, scale(V, si->eta)));
+    H = H.z < 0.0f ? neg(H) : H;
+
+    lobes_t const lb = lobe_weights(si, V.z);
+    int const reflect = L.z * V.z > 0.0f;
+    float const abs_V_H = fabsf(dot(V, H));
+
+    if (lb.diffuse_pr > 0.0f && reflect) {
+        accumulate(&bsdf_pdf, eval_disney_diffuse(si, lb.csheen, V, L, H), lb.dielectric_wt,
+            lb.diffuse_pr);
+    }
+    if (lb.dielectric_pr > 0.0f && reflect) {
+        float const F = (dielectric_fresnel(abs_V_H, 1.0f / si->ior) - lb.F0) / (1.0f - lb.F0);
+        accumulate(&bsdf_pdf,
+            eval_microfacet_reflection(si, V, L, H, mix3(lb.cspec0, splat(1.0f), F)),
+            lb.dielectric_wt, lb.dielectric_pr);
+    }
+    if (lb.metal_pr > 0.0f && reflect) {
+        v3 const F = mix3(si->albedo, splat(1.0f), schlick_weight(abs_V_H));
+        accumulate(&bsdf_pdf, eval_microfacet_reflection(si, V, L, H, F), lb.metal_wt, lb.metal_pr);
+    }
+    if (lb.glass_pr > 0.0f) {
+        float const F = dielectric_fresnel(abs_V_H, si->eta);
+        if (reflect) {
+            accumulate(&bsdf_pdf, eval_microfacet_reflection(si, V, L, H, splat(F)), lb.glass_wt,
+                lb.glass_pr * F);
+        } else {
+            accumulate(&bsdf_pdf, eval_microfacet_refraction(si, V, L, H, splat(F)), lb.glass_wt,
+                lb.glass_pr * (1.0f - F));
+        }
+    }
+    if (lb.clearcoat_pr > 0.0f && reflect) {
+        accumulate(&bsdf_pdf, eval_clearcoat(si, V, L, H), 0.25f * si->clearcoat, lb.clearcoat_pr);
+    }
+    float const cos_l = fabsf(L.z);
+    bsdf_pdf.x *= cos_l;
+    bsdf_pdf.y *= cos_l;
+    bsdf_pdf.z *= cos_l;
+    return bsdf_pdf;
+}
+
+static inline v3 glsl_reflect(v3 I, v3 N) { return sub(I, scale(N, 2.0f * dot(N, I))); }
+static inline v3 glsl_refract(v3 I, v3 N, float eta) {
+    float const d = dot(N, I);
+    float const k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) {
+        return splat(0.0f);
+    }
+    return sub(scale(I, eta), scale(N, eta * d + sqrtf(k)));
+}
+
+/* :250-315 */
+static v3 sample_disney(uint32_t* seed, const state_t* st, const surface_info_t* si, v3 V_world) {
+    v3 L;
+    v3 T, B;
+    v3 const N = st->hit_normal;
+    onb(N, &T, &B);
+    v3 const V = to_local(T, B, N, neg(V_world));
+    lobes_t const lb = lobe_weights(si, V.z);
+    float cdf[5];
+    cdf[0] = lb.diffuse_pr;
+    cdf[1] = cdf[0] + lb.dielectric_pr;
+    cdf[2] = cdf[1] + lb.metal_pr;
+    cdf[3] = cdf[2] + lb.glass_pr;
+    cdf[4] = cdf[3] + lb.clearcoat_pr;
+    float const pr = rand_01(seed);
+    if (pr < cdf[0]) {
+        L = cosine_sample_hemisphere(seed);
+    } else if (pr < cdf[2]) {
+        v3 H = sample_ggx_vndf(seed, V, si->ax, si->ay);
+        if (H.z < 0.0f) {
+            H = neg(H);
+        }
+        L = normalize(glsl_reflect(neg(V), H));
+    } else if (pr < cdf[3]) {
+        v3 H = sample_ggx_vndf(seed, V, si->ax, si->ay);
+        if (H.z < 0.0f) {
+            H = neg(H);
+        }
+        float const F = dielectric_fresnel(fabsf(dot(V, H)), si->eta);
+        float const pr_f = rand_01(seed);
+        if (pr_f < F) {
+            L = normalize(glsl_reflect(neg(V), H));
+        } else {
+            L = normalize(glsl_refract(neg(V), H, si->eta));
+        }
+    } else {
+        v3 H = sample_gtr1(seed, si->clearcoat_gloss);
+        if (H.z < 0.0f) {
+            H = neg(H);
+        }
+        L = normalize(glsl_reflect(neg(V), H));
+    }
+    return to_world(T, B, N, L);
+}
+
+/* ------------------------------------------------------------------------- */
+/* megakernel_raytracer.comp:413-438 */
+static v4 eval_sky_light(const ctx_t* c, ray_t ray) {
+    v4 r = {0, 0, 0, 0};
+    if (c->sc->sky_light < 0) {
+        return r;
+    }
+    const rt_light* sky = &c->sc->lights[c->sc->sky_light];
+    if (sky->emission_tex < 0) {
+        r.x = sky->intensity[0];
+        r.y = sky->intensity[1];
+        r.z = sky->intensity[2];
+        r.w = ONE_OVER_FOUR_PI;
+    } else {
+        float const theta = acosf(clampf(ray.direction.y, -1.0f, 1.0f));
+        float const u = (PI + atan2f(ray.direction.z, ray.direction.x)) * ONE_OVER_TWO_PI;
+        float const v = theta * ONE_OVER_PI;
+        v3 const texel = tone_mapping(texture_rgb(c, sky->emission_tex, u, v));
+        v3 const intensity = from3(sky->intensity);
+        r.x = intensity.x * texel.x;
+        r.y = intensity.y * texel.y;
+        r.z = intensity.z * texel.z;
+        float const total_luminance = sky->direction[0];
+        float const tex_w = sky->direction[1];
+        float const tex_h = sky->direction[2];
+        float const padded_sin_theta = pad_above_zero(sinf(theta));
+        r.w = ((luminance(intensity) / total_luminance) * tex_w * tex_h) /
+              ((float) (2.0 * PI_D * PI_D) * padded_sin_theta);
+    }
+    return r;
+}
+
+/* megakernel_raytracer.comp:440-507 */
+static int sample_light(ctx_t* c, ray_t ray, v3 position, light_sample_t* ls) {
+    ls->intensity = splat(0.0f);
+    ls->pdf = 0.0f;
+    ls->wi = splat(0.0f);
+    ls->type = -1;
+    uint32_t const light_count = c->sc->light_count;
+    float const light_pdf = 1.0f / (float) light_count;
+    const rt_light* light = &c->sc->lights[rand_uint(c->seed, 0, light_count - 1)];
+    float const infinity_light_t_max = (float) ((1.0 / 0.00000000000001) - 0.0001);
+    ls->type = light->type;
+    if (light->type == RT_LIGHT_SKY) {
+        v3 const direction = uniform_sample_hemisphere(c->seed, ray.direction);
+        ray_t shadow_ray;
+        shadow_ray.origin = position;
+        shadow_ray.direction = direction;
+        if (any_hit(c, shadow_ray, infinity_light_t_max)) {
+            return 0;
+        }
+        v4 const ip = eval_sky_light(c, shadow_ray);
+        ls->intensity = V3(ip.x, ip.y, ip.z);
+        ls->pdf = light_pdf * ip.w;
+        ls->wi = direction;
+        return 1;
+    } else if (light->type == RT_LIGHT_DISTANT) {
+        /* empty in the shader */
+    } else if (light->type == RT_LIGHT_AREA_SINGLE_SIDED ||
+               light->type == RT_LIGHT_AREA_DOUBLE_SIDED) {
+        const rt_mesh* mesh = &c->sc->meshes[light->mesh];
+        uint32_t const triangle_i =
+            mesh->triangle_offset + rand_uint(c->seed, 0, mesh->triangle_count - 1);
+        rt_mat4 identity;
+        memset(&identity, 0, sizeof(identity));
+        identity.m[0][0] = identity.m[1][1] = identity.m[2][2] = identity.m[3][3] = 1.0f;
+        const rt_mat4* transform =
+            light->transform >= 0 ? &c->sc->transforms[light->transform] : &identity;
+        m3 const inverse_transform =
+            light->transform >= 0 ? mat3_inverse(mat3_of(transform)) : mat3_identity();
+        const rt_triangle* tri = &c->sc->triangles[triangle_i];
+        v3 const bc = uniform_sample_triangle(c->seed);
+        v3 const local_pos = add(add(scale(from3(tri->a.position_texu), bc.x),
+                                     scale(from3(tri->b.position_texu), bc.y)),
+            scale(from3(tri->c.position_texu), bc.z));
+        v3 const light_sample_pos = mat4_mul_point(transform, local_pos, 1.0f);
+        v3 const local_nor = add(add(scale(from3(tri->a.normal_texv), bc.x),
+                                     scale(from3(tri->b.normal_texv), bc.y)),
+            scale(from3(tri->c.normal_texv), bc.z));
+        v3 const light_sample_nor = mat3_tmul(inverse_transform, local_nor);
+        v3 const light_to_frag = sub(light_sample_pos, position);
+        if (light->type != RT_LIGHT_AREA_DOUBLE_SIDED &&
+            dot(light_to_frag, light_sample_nor) > 0.0f) {
+            return 0;
+        }
+        float const dist = length(light_to_frag);
+        float const dist2 = dist * dist;
+        v3 const direction = divs(light_to_frag, dist);
+        ray_t shadow_ray;
+        shadow_ray.origin = position;
+        shadow_ray.direction = direction;
+        if (any_hit(c, shadow_ray, dist - EPSILON)) {
+            return 0;
+        }
+        v3 intensity = from3(light->intensity);
+        if (light->emission_tex >= 0) {
+            float const u = (bc.x * tri->a.position_texu[3] + bc.y * tri->b.position_texu[3]) +
+                            bc.z * tri->c.position_texu[3];
+            float const v = (bc.x * tri->a.normal_texv[3] + bc.y * tri->b.normal_texv[3]) +
+                            bc.z * tri->c.normal_texv[3];
+            intensity = mulv(intensity, texture_rgb(c, light->emission_tex, u, v));
+        }
+        float const pdf_on_light = 1.0f / light->direction[0];
+        ls->intensity = intensity;
+        ls->pdf = light_pdf * pdf_on_light * (dist2 / fabsf(dot(light_sample_nor, direction)));
+        ls->wi = direction;
+        return 1;
+    }
+    return 0;
+}
+
+/* megakernel_raytracer.comp:509-565 */
+static v3 ray_trace(ctx_t* c, ray_t ray) {
+    v3 radiance = splat(0.0f);
+    v3 throughput = splat(1.0f);
+    state_t st;
+    surface_info_t si;
+    light_sample_t ls;
+    v4 bsdf_pdf = {0, 0, 0, 0};
+    memset(&st, 0, sizeof(st));
+    for (uint32_t depth = 0;; ++depth) {
+        int const hit_any = closest_hit(c, ray, &st);
+        if (!hit_any) {
+            v4 const ip = eval_sky_light(c, ray);
+            if (ip.w > 0.0f) {
+                float const mis = depth > 0 ? power_heuristic(bsdf_pdf.w, ip.w) : 1.0f;
+                radiance = add(radiance, mulv(scale(V3(ip.x, ip.y, ip.z), mis), throughput));
+            }
+            break;
+        }
+        get_surface_info(c, &st, &si);
+        radiance = add(radiance, mulv(si.emission, throughput));
+        if (st.inst_light >= 0) {
+            break;
+        }
+        if (depth == c->max_depth) {
+            break;
+        }
+        /* state.glsl:14-16 */
+        v3 const front_face_normal = st.front_face ? st.hit_normal : neg(st.hit_normal);
+        v3 const shadow_ray_origin = add(st.hit_position, scale(front_face_normal, EPSILON));
+        if (sample_light(c, ray, shadow_ray_origin, &ls)) {
+            int const is_delta = ls.type == RT_LIGHT_DISTANT;
+            bsdf_pdf = eval_disney(&st, &si, ray.direction, ls.wi);
+            if (bsdf_pdf.w > 0.0f) {
+                float const mis = is_delta ? 1.0f : power_heuristic(ls.pdf, bsdf_pdf.w);
+                v3 const f = V3(bsdf_pdf.x, bsdf_pdf.y, bsdf_pdf.z);
+                v3 const contribution = divs(mulv(scale(f, mis), ls.intensity), ls.pdf);
+                radiance = add(radiance, mulv(contribution, throughput));
+            }
+        }
+        v3 const next_direction = sample_disney(c->seed, &st, &si, ray.direction);
+        bsdf_pdf = eval_disney(&st, &si, ray.direction, next_direction);
+        if (bsdf_pdf.w > 0.0f) {
+            throughput = mulv(throughput, divs(V3(bsdf_pdf.x, bsdf_pdf.y, bsdf_pdf.z), bsdf_pdf.w));
+        } else {
+            break;
+        }
+        ray.direction = next_direction;
+        ray.origin = add(st.hit_position, scale(next_direction, EPSILON));
+    }
+    return radiance;
+}
+
+/* megakernel_raytracer.comp:85-100: seed the pixel and build its jittered primary ray. */
+static ray_t primary_ray(const rt_camera* cam, uint32_t width, uint32_t x, uint32_t y,
+    uint32_t random_seed, uint32_t* seed) {
+    v3 const du = from3(cam->pixel_delta_u);
+    v3 const dv = from3(cam->pixel_delta_v);
+    v3 const ul = from3(cam->upper_left_pixel);
+    v3 const pos = from3(cam->position);
+    *seed = hash_combine(random_seed, width * y + x);
+    v3 const pixel = add(add(ul, scale(du, (float) (int) x)), scale(dv, (float) (int) y));
+    float const ox = -0.5f + rand_01(seed);
+    float const oy = -0.5f + rand_01(seed);
+    v3 const offset = add(scale(du, ox), scale(dv, oy));
+    v3 const pixel_sample = add(pixel, offset);
+    ray_t ray;
+    ray.origin = pos;
+    ray.direction = normalize(sub(pixel_sample, pos));
+    return ray;
+}
+
+static int check_params(const rt_scene_desc* sc, const oracle_params* p) {
+    if (!sc || !p || p->width == 0 || p->height == 0 || p->tile_width == 0 ||
+        p->tile_height == 0 || p->width % p->tile_width != 0 ||
+        p->height % p->tile_height != 0 || sc->light_count == 0 || !p->seeds) {
+        return 1;
+    }
+    return 0;
+}
+
+static void rect_of(const oracle_params* p, uint32_t* x0, uint32_t* y0, uint32_t* x1, uint32_t* y1) {
+    if (p->rect_x1 == 0 && p->rect_y1 == 0) {
+        *x0 = 0;
+        *y0 = 0;
+        *x1 = p->width;
+        *y1 = p->height;
+    } else {
+        *x0 = p->rect_x0;
+        *y0 = p->rect_y0;
+        *x1 = p->rect_x1 < p->width ? p->rect_x1 : p->width;
+        *y1 = p->rect_y1 < p->height ? p->rect_y1 : p->height;
+    }
+}
+
+int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
+    const oracle_params* p, float* accum, rt_stats* stats) {
+    if (check_params(scene, p) || !accum) {
+        return 1;
+    }
+    uint32_t x0, y0, x1, y1;
+    rect_of(p, &x0, &y0, &x1, &y1);
+    uint32_t const tiles_x = p->width / p->tile_width;
+    uint32_t const tiles = tiles_x * (p->height / p->tile_height);
+    uint64_t closest = 0, shadow = 0, nodes = 0, tris = 0, max_stack = 0;
+#ifdef _OPENMP
+    if (p->threads > 0) {
+        omp_set_num_threads((int) p->threads);
+    }
+#endif
+#pragma omp parallel reduction(+ : closest, shadow, nodes, tris) reduction(max : max_stack)
+    {
+        counters_t cnt;
+        memset(&cnt, 0, sizeof(cnt));
+        uint32_t* stack = (uint32_t*) malloc(sizeof(uint32_t) * STACK_CAPACITY);
+        uint32_t* candidates = (uint32_t*) malloc(sizeof(uint32_t) * CANDIDATE_CAPACITY);
+        uint32_t seed = 0;
+        ctx_t c;
+        c.sc = scene;
+        c.max_depth = p->max_depth;
+        c.seed = &seed;
+        c.cnt = &cnt;
+        c.stack = stack;
+        c.candidates = candidates;
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t y = y0; y < y1; ++y) {
+            for (uint32_t x = x0; x < x1; ++x) {
+                uint32_t const tile = (y / p->tile_height) * tiles_x + x / p->tile_width;
+                float* px = accum + 4 * ((size_t) y * p->width + x);
+                for (uint32_t pass = 0; pass < p->pass_count; ++pass) {
+                    uint32_t const random_seed = p->seeds[(size_t) pass * tiles + tile];
+                    ray_t const ray = primary_ray(camera, p->width, x, y, random_seed, &seed);
+                    v3 const color = ray_trace(&c, ray);
+                    if (p->preview) {
+                        px[0] = color.x;
+                        px[1] = color.y;
+                        px[2] = color.z;
+                    } else {
+                        px[0] = px[0] + color.x;
+                        px[1] = px[1] + color.y;
+                        px[2] = px[2] + color.z;
+                    }
+                    px[3] = 1.0f;
+                }
+            }
+        }
+        free(stack);
+        free(candidates);
+        closest += cnt.closest_rays;
+        shadow += cnt.shadow_rays;
+        nodes += cnt.nodes;
+        tris += cnt.tris;
+        if (cnt.max_stack > max_stack) {
+            max_stack = cnt.max_stack;
+        }
+    }
+    if (stats) {
+        stats->samples += (uint64_t) (x1 - x0) * (y1 - y0) * p->pass_count;
+        stats->closest_rays += closest;
+        stats->shadow_rays += shadow;
+        stats->nodes_visited += nodes;
+        stats->tris_tested += tris;
+        if (max_stack > stats->max_stack) {
+            stats->max_stack = max_stack;
+        }
+    }
+    return 0;
+}
+
+int oracle_primary_ids(const rt_scene_desc* scene, const rt_camera* camera,
+    const oracle_params* p, uint32_t* instance_ids, uint32_t* triangle_ids, float* hit_t,
+    float* bary) {
+    if (check_params(scene, p) || !instance_ids || !triangle_ids) {
+        return 1;
+    }
+    uint32_t const tiles_x = p->width / p->tile_width;
+#ifdef _OPENMP
+    if (p->threads > 0) {
+        omp_set_num_threads((int) p->threads);
+    }
+#endif
+#pragma omp parallel
+    {
+        counters_t cnt;
+        memset(&cnt, 0, sizeof(cnt));
+        uint32_t* stack = (uint32_t*) malloc(sizeof(uint32_t) * STACK_CAPACITY);
+        uint32_t* candidates = (uint32_t*) malloc(sizeof(uint32_t) * CANDIDATE_CAPACITY);
+        uint32_t seed = 0;
+        ctx_t c;
+        c.sc = scene;
+        c.max_depth = p->max_depth;
+        c.seed = &seed;
+        c.cnt = &cnt;
+        c.stack = stack;
+        c.candidates = candidates;
+#pragma omp for schedule(dynamic, 1)
+        for (uint32_t y = 0; y < p->height; ++y) {
+            for (uint32_t x = 0; x < p->width; ++x) {
+                uint32_t const tile = (y / p->tile_height) * tiles_x + x / p->tile_width;
+                ray_t const ray = primary_ray(camera, p->width, x, y, p->seeds[tile], &seed);
+                closest_t const best = find_closest(&c, ray);
+                size_t const i = (size_t) y * p->width + x;
+                instance_ids[i] = best.instance;
+                triangle_ids[i] = best.triangle;
+                if (hit_t) {
+                    hit_t[i] = best.t_max;
+                }
+                if (bary) {
+                    bary[3 * i + 0] = best.rec.b0;
+                    bary[3 * i + 1] = best.rec.b1;
+                    bary[3 * i + 2] = best.rec.b2;
+                }
+            }
+        }
+        free(stack);
+        free(candidates);
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------- */
+/* probes */
+
+void oracle_rand01_sequence(uint32_t seed, uint32_t n, float* values, uint32_t* states) {
+    for (uint32_t i = 0; i < n; ++i) {
+        float const v = rand_01(&seed);
+        if (values) {
+            values[i] = v;
+        }
+        if (states) {
+            states[i] = seed;
+        }
+    }
+}
+
+uint32_t oracle_hash_combine(uint32_t seed, uint32_t v) { return hash_combine(seed, v); }
+
+uint32_t oracle_rand_uint(uint32_t* seed, uint32_t lo, uint32_t hi) {
+    return rand_uint(seed, lo, hi);
+}
+
+int oracle_hit_aabb(const float box[6], const float origin[3], const float direction[3],
+    float t_min, float t_max) {
+    rt_bvh_node n;
+    memset(&n, 0, sizeof(n));
+    n.x_min = box[0];
+    n.x_max = box[1];
+    n.y_min = box[2];
+    n.y_max = box[3];
+    n.z_min = box[4];
+    n.z_max = box[5];
+    v3 const d = from3(direction);
+    v3 const inv_dir = divv(splat(1.0f), d);
+    int const neg_dir[3] = {d.x < 0.0f, d.y < 0.0f, d.z < 0.0f};
+    return hit_aabb(&n, from3(origin), inv_dir, neg_dir, t_min, t_max);
+}
+
+int oracle_hit_triangle(const float tri[9], const float origin[3], const float direction[3],
+    float t_min, float t_max, float out[4]) {
+    ray_t ray;
+    ray.origin = from3(origin);
+    ray.direction = from3(direction);
+    hit_record_t const rec =
+        hit_triangle(from3(tri), from3(tri + 3), from3(tri + 6), ray, t_min, t_max);
+    if (out) {
+        out[0] = rec.b0;
+        out[1] = rec.b1;
+        out[2] = rec.b2;
+        out[3] = rec.t;
+    }
+    return rec.hit;
+}
+
+int oracle_hit_triangle_quick(const float tri[9], const float origin[3],
+    const float direction[3], float t_min, float t_max) {
+    return oracle_hit_triangle(tri, origin, direction, t_min, t_max, NULL);
+}
+
+static void probe_surface(const rt_material* m, int front_face, const float normal[3],
+    state_t* st, surface_info_t* si) {
+    rt_scene_desc sc;
+    memset(&sc, 0, sizeof(sc));
+    sc.materials = m;
+    sc.material_count = 1;
+    ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.sc = &sc;
+    memset(st, 0, sizeof(*st));
+    st->hit_normal = from3(normal);
+    st->front_face = front_face;
+    st->inst_material = 0;
+    st->inst_light = -1;
+    st->inst_medium = -1;
+    get_surface_info(&c, st, si);
+}
+
+void oracle_eval_disney(const rt_material* material, int front_face, const float normal[3],
+    const float v_in[3], const float l[3], float out[4]) {
+    state_t st;
+    surface_info_t si;
+    probe_surface(material, front_face, normal, &st, &si);
+    v4 const r = eval_disney(&st, &si, from3(v_in), from3(l));
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+    out[3] = r.w;
+}
+
+void oracle_sample_disney(const rt_material* material, int front_face, const float normal[3],
+    const float v_in[3], uint32_t* seed, float out_l[3]) {
+    state_t st;
+    surface_info_t si;
+    probe_surface(material, front_face, normal, &st, &si);
+    v3 const r = sample_disney(seed, &st, &si, from3(v_in));
+    out_l[0] = r.x;
+    out_l[1] = r.y;
+    out_l[2] = r.z;
+}
+
+void oracle_sample_texture(const rt_texture* texture, float u, float v, float out[4]) {
+    v4 const r = sample_texture(texture, u, v);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+    out[3] = r.w;
+}
