@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the path-tracing hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+
+One step = one launch of the path-tracing kernel over the whole 1280x720 frame at
+max_depth 7, tracing --spp-per-step passes of every pixel (synthetic = scene snapshot already
+resident in HBM, seeds resident, accumulator resident).  The reported value is
+pixel-samples per second over all GPUs, in Msamples/s; Mrays/s comes from the device ray
+counters of the same timed region.
+
+N > 1: one process per GPU (torchrun); each rank traces its own pass range of the same frame
+(global pass index in the seed schedule, scene replicated) and the accumulators are summed
+onto rank 0 with one RCCL reduce inside the timed region.  Work per GPU is fixed: weak
+scaling.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from raytracing_amd import hip, host, scenes  # noqa: E402
+from raytracing_amd.distributed import new_accumulator, reduce_accumulator  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak (spec)
+
+# Algorithmic bytes (roofline numerator), per unit of work:
+NODE_BYTES = 32       # 6-float box + 2 topology words: the minimum for a binary BVH node
+TRI_BYTES = 36        # 9 position floats
+HIT_BYTES = 300       # shading fetch per closest hit: full triangle 96 + material 96 +
+#                       instance 20 + transform 64 + descriptors/light 24
+FRAME_BYTES = 32      # accumulator read-modify-write per pixel per launch
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--scene", default="hyperion_rect_light")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--max-depth", type=int, default=7)
+    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--accel", choices=["rebuilt", "reference"], default="rebuilt")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0,
+                    help="target duration of the CPU baseline sample")
+    return ap.parse_args()
+
+
+def load_constants(scene_name):
+    path = os.path.join(ROOT, "tests", "golden", "workload_constants.json")
+    with open(path) as f:
+        return json.load(f)[scene_name]
+
+
+def cpu_baseline(sc, cam, args, tile, target_seconds):
+    """Times the CPU restatement (the oracle) on a bounded sample of the same workload."""
+    import oracle
+    threads = min(os.cpu_count() or 1, int(os.environ.get("OMP_NUM_THREADS", "16")))
+    tiles = (args.width // tile[0]) * (args.height // tile[1])
+    seeds = host.seed_schedule(0, 1, tiles)
+    t0 = time.perf_counter()
+    oracle.render(sc.desc, cam, args.width, args.height, args.max_depth, tile, seeds,
+                  threads=threads)
+    one = time.perf_counter() - t0
+    passes = max(1, min(64, int(target_seconds / max(one, 1e-3))))
+    seeds = host.seed_schedule(0, passes, tiles)
+    t0 = time.perf_counter()
+    _, st = oracle.render(sc.desc, cam, args.width, args.height, args.max_depth, tile, seeds,
+                          threads=threads)
+    dt = time.perf_counter() - t0
+    return {
+        "value": args.width * args.height * passes / dt / 1e6,
+        "unit": "Msamples/s",
+        "cores": threads,
+        "kind": "port",
+        "sample": f"{passes} passes of the full {args.width}x{args.height} frame, same scene, "
+                  f"seed schedule and max_depth; {dt:.1f} s; OpenMP over image rows",
+        "mrays_per_s": (st["closest_rays"] + st["shadow_rays"]) / dt / 1e6,
+    }
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=torch.device("cuda", local_rank))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE is {world}: launch with torchrun")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+
+    tile = (args.width // 10, args.height // 10)  # 128x72 at 1280x720, as mustang_red.json
+    sc = scenes.load_snapshot(args.scene)
+    cam = sc.camera(args.width, args.height)
+    accel = hip.ACCEL_REBUILT if args.accel == "rebuilt" else hip.ACCEL_REFERENCE
+    r = hip.HipRenderer(args.width, args.height, args.max_depth, tile, device=local_rank,
+                        accel=accel)
+    r.upload_scene(sc.desc)
+
+    spp = args.spp_per_step
+    total_steps = args.warmup + args.steps
+    passes_per_rank = total_steps * spp
+    first_pass = rank * passes_per_rank  # global pass index: ranks trace disjoint passes
+    seeds = host.seed_schedule(first_pass, passes_per_rank, r.tile_count)
+    r.upload_seeds(seeds, first_pass)
+
+    accum = new_accumulator(args.height, args.width, device)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        r.render(cam, first_pass + i * spp, spp, accum_dev=accum.data_ptr(), stream=stream)
+
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    r.stats(reset=True)
+    accum.zero_()
+    accum[..., 3] = 1.0
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    reduce_accumulator(accum, dst=0)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    st = r.stats()
+    kernel_ms, launches = r.kernel_time()
+    times = torch.tensor([elapsed], dtype=torch.float64, device=device)
+    counts = torch.tensor([st["samples"], st["closest_rays"], st["shadow_rays"],
+                           st["closest_hits"]], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(times, op=dist.ReduceOp.MAX)
+        dist.all_reduce(counts, op=dist.ReduceOp.SUM)
+    elapsed = float(times.item())
+    samples, closest, shadow, hits = (float(v) for v in counts.tolist())
+
+    if rank == 0:
+        image_ok = bool(torch.isfinite(accum).all().item())
+        k = load_constants(args.scene) if args.scene in ("cornell_box", "hyperion_rect_light") \
+            else None
+        roofline = None
+        if k is not None and launches > 0:
+            # per launch, this rank: rays counted on the device x the reference-BVH per-ray
+            # node/triangle counts measured by the oracle at this configuration
+            rays_l = (st["closest_rays"] + st["shadow_rays"]) / launches
+            bytes_l = (rays_l * (k["nodes_per_ray"] * NODE_BYTES + k["tris_per_ray"] * TRI_BYTES)
+                       + st["closest_hits"] / launches * HIT_BYTES
+                       + args.width * args.height * FRAME_BYTES)
+            achieved = bytes_l / (kernel_ms * 1e-3) / 1e9
+            roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "kernel": "path_trace_kernel", "kernel_avg_ms": kernel_ms,
+                        "launches": launches, "algorithmic_bytes_per_launch": bytes_l}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            cpu = cpu_baseline(sc, cam, args, tile, args.cpu_seconds)
+        line = {
+            "metric": "Msamples/s at 1280x720 max_depth 7",
+            "value": samples / elapsed / 1e6,
+            "unit": "Msamples/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{args.scene} (reference scene, snapshot of its loader output), "
+                            f"{args.width}x{args.height}, max_depth {args.max_depth}, "
+                            f"{spp} spp per step, accel={args.accel}",
+                "samples_per_step_per_gpu": args.width * args.height * spp,
+                "parallelism": f"sample-range split x{world}, scene replicated, "
+                               "one RCCL sum-reduce" if world > 1 else "single GPU",
+            },
+            "mrays_per_s": (closest + shadow) / elapsed / 1e6,
+            "rays_per_sample": (closest + shadow) / max(samples, 1.0),
+            "image_finite": image_ok,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    r.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+/*
+ * C ABI of the MI355X (gfx950) path-tracing library, librt_hip.so.
+ *
+ * This is the drop-in boundary for the reference's ray-tracing back end: the
+ * calls below are what the six `renderer` callbacks
+ * (src/renderer/renderer.h:5-17, implemented for Vulkan in
+ * src/renderer/megakernel_raytracer.cpp:525-822) need from a device layer.
+ * Only plain pointers, sizes and PODs cross it; every function returns 0 on
+ * success and a non-zero code on failure, with rt_hip_last_error() holding a
+ * message for the calling thread.  A renderer handle is used from one host
+ * thread at a time (the reference's callbacks are never re-entered).
+ *
+ * Buffers named *_dev are device pointers on the renderer's GPU; everything
+ * else is host memory that the call has finished reading when it returns.
+ */
+#ifndef RT_HIP_H
+#define RT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#include "rt_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct rt_hip_renderer rt_hip_renderer;
+
+enum {
+    /* Walk the uploaded TLAS/BLAS nodes in the reference shader's order
+     * (megakernel_raytracer.comp:184-276): hit ids, t and barycentrics are
+     * bit-identical to the reference algorithm, ties included. */
+    RT_HIP_ACCEL_REFERENCE = 0,
+    /* Rebuild the acceleration structure at upload into a layout made for the
+     * GPU (see rt_hip_upload_scene).  Same triangles and the same
+     * intersection arithmetic, different visiting order: results differ only
+     * where two hits tie at the same t or a box test grazes. */
+    RT_HIP_ACCEL_REBUILT = 1
+};
+
+enum {
+    RT_HIP_FLAG_COUNT_NODES = 1u /* also count BVH nodes fetched / triangles tested */
+};
+
+#define RT_HIP_MISS 0xFFFFFFFFu
+
+typedef struct rt_hip_config {
+    uint32_t width, height;           /* render_options.resolution_x/y */
+    uint32_t max_depth;               /* render_options.max_depth */
+    uint32_t tile_width, tile_height; /* render_options.tile_width/height */
+    int32_t device;                   /* HIP device ordinal; -1 = current device */
+    uint32_t accel;                   /* RT_HIP_ACCEL_* */
+    uint32_t flags;                   /* RT_HIP_FLAG_* */
+} rt_hip_config;
+
+/* Replaces megakernel_raytracer_initialize (megakernel_raytracer.cpp:525-553)
+ * plus the accumulation / preview image creation of :314-324.  Allocates the
+ * W x H RGBA32F accumulator and the (W/10) x (H/10) preview image. */
+int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out);
+
+/* Replaces prepare_megakernel_raytracer_resources (:269-467): copies every
+ * buffer the compute pass binds to the device.  May be called again to
+ * replace the scene.  With RT_HIP_ACCEL_REBUILT the TLAS/BLAS are rebuilt
+ * from the uploaded instances and triangles; reported ids still index the
+ * uploaded (reference-ordered) arrays. */
+int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene);
+
+/* Makes the per-dispatch random_seed words (push constant, :650-658) of passes
+ * [first_pass, first_pass + pass_count) resident: seeds[(p - first_pass) *
+ * tiles + tile], tiles numbered row-major. */
+int rt_hip_upload_seeds(rt_hip_renderer* r, const uint32_t* seeds, uint32_t first_pass,
+    uint32_t pass_count);
+
+/* Replaces clearColorImage of the accumulation image (:628-649) and resets
+ * the pass counter.  accum_dev = NULL means the renderer's own accumulator. */
+int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream);
+
+/* The hot path.  Replaces pass_count x tiles dispatchBase calls (:650-669):
+ * traces passes [first_pass, first_pass + pass_count) of every pixel in
+ * rect = {x0, y0, x1, y1} (NULL = whole frame) and adds them to the
+ * accumulator in pass order, exactly as that many sequential dispatches
+ * would.  Seeds must have been uploaded for those passes.  Asynchronous on
+ * `stream` (a hipStream_t; NULL = the default stream).
+ * accum_dev: W*H*4 floats on the device, or NULL for the renderer's own. */
+int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
+    uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream);
+
+/* One reference dispatch: one pass of one tile with an explicit random_seed
+ * (:650-666), into the renderer's own accumulator.  When the tile is the last
+ * of the frame the pass counter advances (:667-669). */
+int rt_hip_render_tile(rt_hip_renderer* r, const rt_camera* camera, uint32_t random_seed,
+    uint32_t tile_x, uint32_t tile_y, void* stream);
+
+/* The camera.dirty branch (:600-619): one sample per pixel of the
+ * (W/10) x (H/10) preview image, stored (not accumulated); resets the
+ * accumulation state like the reference does. */
+int rt_hip_render_preview(rt_hip_renderer* r, const rt_camera* preview_camera,
+    uint32_t random_seed, void* stream);
+
+/* closest_hit() of every pixel's primary ray of pass `pass` (seeds must be
+ * resident).  Host outputs, W*H each (bary: 3 floats per pixel); any may be
+ * NULL.  Misses report RT_HIP_MISS ids and t = 1e14. */
+int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pass,
+    uint32_t* instance_ids, uint32_t* triangle_ids, float* hit_t, float* bary);
+
+/* Synchronises `stream`, then copies the renderer's own accumulator (W*H*4 floats)
+ * / preview image ((W/10)*(H/10)*4 floats) to the host.  *passes = number
+ * of complete passes accumulated so far (the reference's accumulation_counter). */
+int rt_hip_read_accum(rt_hip_renderer* r, float* rgba, uint32_t* passes, void* stream);
+int rt_hip_read_preview(rt_hip_renderer* r, float* rgba, void* stream);
+
+/* Device address of the renderer's own accumulator (for a collective). */
+int rt_hip_accum_ptr(rt_hip_renderer* r, void** accum_dev);
+
+/* Tell the renderer how many complete passes its accumulator holds (used
+ * after an external reduce into it). */
+int rt_hip_set_passes(rt_hip_renderer* r, uint32_t passes);
+
+/* Work counters since creation or the last reset; synchronises the device.
+ * seconds = device time of the rt_hip_render* launches, from HIP events
+ * recorded on the launch stream. */
+int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset);
+
+/* Average device time of the launches of the main kernel since the last
+ * reset, in milliseconds, and how many launches that covers. */
+int rt_hip_kernel_time(rt_hip_renderer* r, double* avg_ms, uint32_t* launches);
+
+/* Replaces megakernel_raytracer_destroy (:793-813). */
+int rt_hip_destroy(rt_hip_renderer* r);
+
+const char* rt_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* RT_HIP_H */

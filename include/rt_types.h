@@ -161,6 +161,7 @@ typedef struct rt_stats {
     uint64_t samples;       /* pixel-samples traced */
     uint64_t closest_rays;  /* closest_hit() calls */
     uint64_t shadow_rays;   /* any_hit() calls */
+    uint64_t closest_hits;  /* closest_hit() calls that returned a hit */
     uint64_t nodes_visited; /* BVH nodes fetched (TLAS + BLAS) */
     uint64_t tris_tested;   /* ray/triangle tests */
     uint64_t max_stack;     /* deepest traversal stack seen */

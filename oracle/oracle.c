@@ -153,7 +153,7 @@ typedef struct { v3 origin, direction; } ray_t;
 
 /* per-thread work counters */
 typedef struct {
-    uint64_t closest_rays, shadow_rays, nodes, tris, max_stack;
+    uint64_t closest_rays, shadow_rays, closest_hits, nodes, tris, max_stack;
 } counters_t;
 
 typedef struct {
@@ -530,6 +530,7 @@ static int closest_hit(ctx_t* c, ray_t ray, state_t* st) {
     if (best.t_max == RT_INFINITY) {
         return 0;
     }
+    ++c->cnt->closest_hits;
     const rt_instance* inst = &c->sc->instances[best.instance];
     const rt_triangle* tri = &c->sc->triangles[best.triangle];
     v3 const a = from3(tri->a.position_texu);
@@ -1191,13 +1192,13 @@ int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
     rect_of(p, &x0, &y0, &x1, &y1);
     uint32_t const tiles_x = p->width / p->tile_width;
     uint32_t const tiles = tiles_x * (p->height / p->tile_height);
-    uint64_t closest = 0, shadow = 0, nodes = 0, tris = 0, max_stack = 0;
+    uint64_t closest = 0, shadow = 0, hits = 0, nodes = 0, tris = 0, max_stack = 0;
 #ifdef _OPENMP
     if (p->threads > 0) {
         omp_set_num_threads((int) p->threads);
     }
 #endif
-#pragma omp parallel reduction(+ : closest, shadow, nodes, tris) reduction(max : max_stack)
+#pragma omp parallel reduction(+ : closest, shadow, hits, nodes, tris) reduction(max : max_stack)
     {
         counters_t cnt;
         memset(&cnt, 0, sizeof(cnt));
@@ -1237,6 +1238,7 @@ int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
         free(candidates);
         closest += cnt.closest_rays;
         shadow += cnt.shadow_rays;
+        hits += cnt.closest_hits;
         nodes += cnt.nodes;
         tris += cnt.tris;
         if (cnt.max_stack > max_stack) {
@@ -1247,6 +1249,7 @@ int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
         stats->samples += (uint64_t) (x1 - x0) * (y1 - y0) * p->pass_count;
         stats->closest_rays += closest;
         stats->shadow_rays += shadow;
+        stats->closest_hits += hits;
         stats->nodes_visited += nodes;
         stats->tris_tested += tris;
         if (max_stack > stats->max_stack) {

@@ -1,0 +1,338 @@
+// Binned-SAH builder for the rebuilt acceleration structure.
+//
+// The host BVH that arrives through the C ABI keeps the reference builder's
+// shape, whose split search never moves off "bucket 0 | rest"
+// (src/renderer/bvh.cpp:198-205): its trees are tens of levels deeper than
+// needed (61 levels for a 15 872-triangle sphere).  Traversal cost on the GPU
+// is dominated by dependent node fetches, so the library builds its own trees
+// from the uploaded triangles and instances.  Ids reported by the kernels
+// still refer to the uploaded arrays (tri_pos::ref_index,
+// instance_rec::ref_index).
+#include "accel_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <stdexcept>
+
+namespace rtd {
+namespace {
+
+struct box3 {
+    float lo[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(),
+        std::numeric_limits<float>::max()};
+    float hi[3] = {std::numeric_limits<float>::lowest(), std::numeric_limits<float>::lowest(),
+        std::numeric_limits<float>::lowest()};
+    void grow(float const p[3]) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], p[a]);
+            hi[a] = std::max(hi[a], p[a]);
+        }
+    }
+    void grow(box3 const& b) {
+        for (int a = 0; a < 3; ++a) {
+            lo[a] = std::min(lo[a], b.lo[a]);
+            hi[a] = std::max(hi[a], b.hi[a]);
+        }
+    }
+    float half_area() const {
+        float const dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0.0f) {
+            return 0.0f;  // empty
+        }
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct build_prim {
+    box3 bounds;
+    float centroid[3];
+    uint32_t id;
+};
+
+constexpr int kBins = 16;
+constexpr uint32_t kDepthLimit = 40;   // beyond this, split by object median
+constexpr float kTraversalCost = 1.2f;
+constexpr float kIntersectCost = 1.0f;
+
+int32_t encode_leaf(uint32_t first, uint32_t count) {
+    return (int32_t) ~((first << 3) | (count - 1u));
+}
+
+class tree_builder {
+public:
+    // emit_leaf(prims, count) appends the leaf's payload and returns its first index.
+    template <typename EMIT>
+    int32_t build(std::vector<wide_node>& nodes, build_prim* prims, uint32_t count,
+        uint32_t max_leaf, uint32_t depth, EMIT& emit_leaf, uint32_t& deepest) {
+        deepest = std::max(deepest, depth);
+        if (count <= max_leaf && (count == 1 || !worth_splitting(prims, count))) {
+            return encode_leaf(emit_leaf(prims, count), count);
+        }
+        uint32_t const mid = partition(prims, count, depth);
+        uint32_t const self = (uint32_t) nodes.size();
+        nodes.push_back(wide_node{});
+        box3 b0, b1;
+        for (uint32_t i = 0; i < mid; ++i) {
+            b0.grow(prims[i].bounds);
+        }
+        for (uint32_t i = mid; i < count; ++i) {
+            b1.grow(prims[i].bounds);
+        }
+        int32_t const c0 = build(nodes, prims, mid, max_leaf, depth + 1, emit_leaf, deepest);
+        int32_t const c1 =
+            build(nodes, prims + mid, count - mid, max_leaf, depth + 1, emit_leaf, deepest);
+        wide_node& n = nodes[self];
+        n.lo0x = b0.lo[0]; n.lo0y = b0.lo[1]; n.lo0z = b0.lo[2];
+        n.hi0x = b0.hi[0]; n.hi0y = b0.hi[1]; n.hi0z = b0.hi[2];
+        n.lo1x = b1.lo[0]; n.lo1y = b1.lo[1]; n.lo1z = b1.lo[2];
+        n.hi1x = b1.hi[0]; n.hi1y = b1.hi[1]; n.hi1z = b1.hi[2];
+        n.child0 = c0;
+        n.child1 = c1;
+        return (int32_t) self;
+    }
+
+private:
+    struct split_choice {
+        int axis = -1;
+        int bin = 0;
+        float cost = std::numeric_limits<float>::max();
+        float lo = 0.0f, scale = 0.0f;
+    };
+
+    static split_choice best_split(build_prim const* prims, uint32_t count) {
+        box3 cb;
+        for (uint32_t i = 0; i < count; ++i) {
+            cb.grow(prims[i].centroid);
+        }
+        split_choice best;
+        for (int axis = 0; axis < 3; ++axis) {
+            float const extent = cb.hi[axis] - cb.lo[axis];
+            if (!(extent > 0.0f)) {
+                continue;
+            }
+            float const scale = (float) kBins / extent;
+            box3 bin_box[kBins];
+            uint32_t bin_count[kBins] = {};
+            for (uint32_t i = 0; i < count; ++i) {
+                int b = (int) ((prims[i].centroid[axis] - cb.lo[axis]) * scale);
+                b = std::min(std::max(b, 0), kBins - 1);
+                bin_box[b].grow(prims[i].bounds);
+                ++bin_count[b];
+            }
+            float right_area[kBins];
+            uint32_t right_count[kBins];
+            box3 acc;
+            uint32_t n = 0;
+            for (int b = kBins - 1; b > 0; --b) {
+                acc.grow(bin_box[b]);
+                n += bin_count[b];
+                right_area[b] = acc.half_area();
+                right_count[b] = n;
+            }
+            box3 left;
+            uint32_t left_n = 0;
+            for (int b = 0; b < kBins - 1; ++b) {
+                left.grow(bin_box[b]);
+                left_n += bin_count[b];
+                if (left_n == 0 || right_count[b + 1] == 0) {
+                    continue;
+                }
+                float const cost = left.half_area() * (float) left_n +
+                                   right_area[b + 1] * (float) right_count[b + 1];
+                if (cost < best.cost) {
+                    best.cost = cost;
+                    best.axis = axis;
+                    best.bin = b;
+                    best.lo = cb.lo[axis];
+                    best.scale = scale;
+                }
+            }
+        }
+        return best;
+    }
+
+    static bool worth_splitting(build_prim const* prims, uint32_t count) {
+        box3 all;
+        for (uint32_t i = 0; i < count; ++i) {
+            all.grow(prims[i].bounds);
+        }
+        float const area = all.half_area();
+        if (!(area > 0.0f)) {
+            return false;
+        }
+        split_choice const s = best_split(prims, count);
+        if (s.axis < 0) {
+            return false;
+        }
+        float const split_cost = kTraversalCost + kIntersectCost * s.cost / area;
+        return split_cost < kIntersectCost * (float) count;
+    }
+
+    static uint32_t partition(build_prim* prims, uint32_t count, uint32_t depth) {
+        if (depth < kDepthLimit) {
+            split_choice const s = best_split(prims, count);
+            if (s.axis >= 0) {
+                auto const it = std::partition(prims, prims + count, [&](build_prim const& p) {
+                    int b = (int) ((p.centroid[s.axis] - s.lo) * s.scale);
+                    b = std::min(std::max(b, 0), kBins - 1);
+                    return b <= s.bin;
+                });
+                uint32_t const mid = (uint32_t) (it - prims);
+                if (mid > 0 && mid < count) {
+                    return mid;
+                }
+            }
+        }
+        // Object median along the widest centroid axis: bounds the depth.
+        box3 cb;
+        for (uint32_t i = 0; i < count; ++i) {
+            cb.grow(prims[i].centroid);
+        }
+        int axis = 0;
+        float widest = cb.hi[0] - cb.lo[0];
+        for (int a = 1; a < 3; ++a) {
+            if (cb.hi[a] - cb.lo[a] > widest) {
+                widest = cb.hi[a] - cb.lo[a];
+                axis = a;
+            }
+        }
+        uint32_t const mid = count / 2;
+        std::nth_element(prims, prims + mid, prims + count,
+            [axis](build_prim const& a, build_prim const& b) {
+                return a.centroid[axis] < b.centroid[axis];
+            });
+        return mid;
+    }
+};
+
+void set_centroid(build_prim& p) {
+    for (int a = 0; a < 3; ++a) {
+        p.centroid[a] = 0.5f * (p.bounds.lo[a] + p.bounds.hi[a]);
+    }
+}
+
+}  // namespace
+
+built_accel build_wide_accel(rt_scene_desc const& sc) {
+    if (sc.instance_count == 0 || sc.mesh_count == 0 || sc.triangle_count == 0) {
+        throw std::runtime_error("accel: empty scene");
+    }
+    if (sc.triangle_count >= (1u << 28)) {
+        throw std::runtime_error("accel: too many triangles for the leaf encoding");
+    }
+    built_accel out;
+    out.tris.reserve(sc.triangle_count);
+    tree_builder builder;
+
+    // One BLAS per mesh.
+    std::vector<int32_t> mesh_root(sc.mesh_count);
+    std::vector<box3> mesh_bounds(sc.mesh_count);
+    uint32_t deepest_blas = 0;
+    std::vector<build_prim> prims;
+    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
+        rt_mesh const& mesh = sc.meshes[m];
+        if (mesh.triangle_count == 0 ||
+            (uint64_t) mesh.triangle_offset + mesh.triangle_count > sc.triangle_count) {
+            throw std::runtime_error("accel: mesh triangle range out of bounds");
+        }
+        prims.resize(mesh.triangle_count);
+        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+            rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
+            build_prim& p = prims[t];
+            p.bounds = box3{};
+            p.bounds.grow(tri.a.position_texu);
+            p.bounds.grow(tri.b.position_texu);
+            p.bounds.grow(tri.c.position_texu);
+            set_centroid(p);
+            p.id = mesh.triangle_offset + t;
+            mesh_bounds[m].grow(p.bounds);
+        }
+        auto emit = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
+            uint32_t const first = (uint32_t) out.tris.size();
+            for (uint32_t i = 0; i < count; ++i) {
+                rt_triangle const& tri = sc.triangles[leaf[i].id];
+                tri_pos tp{};
+                tp.ax = tri.a.position_texu[0];
+                tp.ay = tri.a.position_texu[1];
+                tp.az = tri.a.position_texu[2];
+                tp.ref_index = leaf[i].id;
+                tp.bx = tri.b.position_texu[0];
+                tp.by = tri.b.position_texu[1];
+                tp.bz = tri.b.position_texu[2];
+                tp.cx = tri.c.position_texu[0];
+                tp.cy = tri.c.position_texu[1];
+                tp.cz = tri.c.position_texu[2];
+                out.tris.push_back(tp);
+            }
+            return first;
+        };
+        uint32_t deepest = 0;
+        mesh_root[m] = builder.build(
+            out.nodes, prims.data(), mesh.triangle_count, 4u, 0u, emit, deepest);
+        deepest_blas = std::max(deepest_blas, deepest);
+    }
+
+    // TLAS over the world boxes of the instances (8 transformed corners of the
+    // mesh box, padded so rounding cannot cut a hit off).
+    prims.resize(sc.instance_count);
+    for (uint32_t i = 0; i < sc.instance_count; ++i) {
+        rt_instance const& inst = sc.instances[i];
+        if (inst.mesh >= sc.mesh_count ||
+            (inst.transform >= 0 && (uint32_t) inst.transform >= sc.transform_count)) {
+            throw std::runtime_error("accel: instance refers to a missing mesh or transform");
+        }
+        box3 const& mb = mesh_bounds[inst.mesh];
+        box3 wb;
+        for (int corner = 0; corner < 8; ++corner) {
+            float const p[3] = {(corner & 1) ? mb.hi[0] : mb.lo[0],
+                (corner & 2) ? mb.hi[1] : mb.lo[1], (corner & 4) ? mb.hi[2] : mb.lo[2]};
+            float w[3] = {p[0], p[1], p[2]};
+            if (inst.transform >= 0) {
+                rt_mat4 const& m = sc.transforms[inst.transform];
+                for (int r = 0; r < 3; ++r) {
+                    w[r] = m.m[0][r] * p[0] + m.m[1][r] * p[1] + m.m[2][r] * p[2] + m.m[3][r];
+                }
+            }
+            wb.grow(w);
+        }
+        for (int a = 0; a < 3; ++a) {
+            float const pad = 1e-5f * (wb.hi[a] - wb.lo[a]) +
+                              4e-7f * std::max(std::fabs(wb.lo[a]), std::fabs(wb.hi[a])) + 1e-30f;
+            wb.lo[a] -= pad;
+            wb.hi[a] += pad;
+        }
+        prims[i].bounds = wb;
+        set_centroid(prims[i]);
+        prims[i].id = i;
+    }
+    auto emit_instance = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
+        (void) count;  // TLAS leaves hold exactly one instance
+        uint32_t const first = (uint32_t) out.instances.size();
+        rt_instance const& inst = sc.instances[leaf[0].id];
+        instance_rec rec{};
+        if (inst.transform >= 0) {
+            rt_mat4 const& inv = sc.inverse_transforms[inst.transform];
+            for (int c = 0; c < 4; ++c) {
+                for (int r = 0; r < 3; ++r) {
+                    rec.m[c * 3 + r] = inv.m[c][r];
+                }
+            }
+            rec.has_transform = 1;
+        } else {
+            rec.m[0] = rec.m[4] = rec.m[8] = 1.0f;
+            rec.has_transform = 0;
+        }
+        rec.blas_root = mesh_root[inst.mesh];
+        rec.ref_index = leaf[0].id;
+        out.instances.push_back(rec);
+        return first;
+    };
+    uint32_t deepest_tlas = 0;
+    out.tlas_root = builder.build(
+        out.nodes, prims.data(), sc.instance_count, 1u, 0u, emit_instance, deepest_tlas);
+    out.max_stack_bound = deepest_tlas + 1u + deepest_blas;
+    return out;
+}
+
+}  // namespace rtd

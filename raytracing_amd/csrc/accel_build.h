@@ -1,0 +1,26 @@
+// Host-side construction of the GPU-oriented acceleration structure used by
+// RT_HIP_ACCEL_REBUILT (see rt_traverse_fast.h for the layout rationale).
+#pragma once
+
+#include <cstdint>
+#include <vector>
+
+#include "rt_device_scene.h"
+#include "rt_types.h"
+
+namespace rtd {
+
+struct built_accel {
+    std::vector<wide_node> nodes;         // every BLAS, then the TLAS
+    std::vector<tri_pos> tris;            // leaf order; ref_index -> uploaded triangles[]
+    std::vector<instance_rec> instances;  // TLAS leaf order
+    int32_t tlas_root = 0;                // node index, or an encoded leaf
+    uint32_t max_stack_bound = 0;         // TLAS depth + 1 + deepest BLAS depth
+};
+
+// Builds binned-SAH binary trees over the uploaded triangles (one BLAS per
+// mesh, shared by its instances) and over the instances' world boxes.
+// Throws std::runtime_error on malformed input.
+built_accel build_wide_accel(rt_scene_desc const& scene);
+
+}  // namespace rtd

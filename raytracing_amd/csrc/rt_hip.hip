@@ -1,0 +1,898 @@
+// librt_hip.so: kernels and the C ABI declared in include/rt_hip.h.
+//
+// Built for gfx950 only, with -ffp-contract=off: every fused multiply-add in
+// the kernels is written explicitly (rt_traverse_fast.h), everything else is
+// plain IEEE binary32 so results can be compared with the CPU oracle.
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "accel_build.h"
+#include "rt_hip.h"
+#include "rt_path.h"
+
+using namespace rtd;
+
+// ---------------------------------------------------------------------------
+// kernels
+
+namespace {
+
+constexpr uint32_t kCounterWords = 7;  // samples, closest, shadow, hits, nodes, tris, max_stack
+constexpr uint32_t kPreviewRatio = 10; // src/renderer/megakernel_raytracer.cpp:54
+
+// Pixel owned by this lane: waves cover 8x8 pixel blocks of the rectangle, and
+// consecutive block ids that share an XCD (ids equal mod 8) are given
+// neighbouring screen blocks so each XCD's L2 sees a compact part of the scene.
+__device__ __forceinline__ bool lane_pixel(render_params const& p, uint32_t& x, uint32_t& y) {
+    uint32_t const blocks_x = (p.x1 - p.x0 + 7u) / 8u;
+    uint32_t const total = gridDim.x;
+    uint32_t const xcd = blockIdx.x % 8u;
+    uint32_t const q = total / 8u, r = total % 8u;
+    uint32_t const start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
+    uint32_t const block = start + blockIdx.x / 8u;
+    uint32_t const bx = block % blocks_x;
+    uint32_t const by = block / blocks_x;
+    uint32_t const lane = threadIdx.x;
+    x = p.x0 + bx * 8u + (lane & 7u);
+    y = p.y0 + by * 8u + (lane >> 3);
+    return x < p.x1 && y < p.y1;
+}
+
+template <int ACCEL, bool COUNT>
+__global__ void __launch_bounds__(64) path_trace_kernel(render_params const p) {
+    __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
+    fast_stack stk;
+    stk.lds = lds_stack + threadIdx.x;
+
+    uint32_t x, y;
+    if (!lane_pixel(p, x, y)) {
+        return;
+    }
+    scene_dev const& sc = p.sc;
+    float* const px = p.accum + 4u * ((size_t) y * p.frame_width + x);
+    f3 acc = splat3(0.0f);
+    if (!p.preview) {
+        float4 const old = *reinterpret_cast<const float4*>(px);
+        acc = mk3(old.x, old.y, old.z);
+    }
+
+    trace_counters cnt;
+    uint32_t closest_rays = 0, shadow_rays = 0, closest_hits = 0;
+
+    uint32_t pass = 0;
+    uint32_t seed;
+    f3 origin, direction;
+    f3 radiance = splat3(0.0f);
+    f3 throughput = splat3(1.0f);
+    float last_bsdf_pdf = 0.0f;
+    uint32_t depth = 0;
+    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, origin, direction);
+
+    for (;;) {
+        bool path_done = false;
+        hit_result hr;
+        ++closest_rays;
+        bool const hit_any = trace_closest<ACCEL, COUNT>(sc, stk, origin, direction, hr, cnt);
+        if (!hit_any) {
+            // megakernel_raytracer.comp:518-527
+            f4 const ip = eval_sky_light(sc, direction);
+            if (ip.w > 0.0f) {
+                float const mis = depth > 0u ? power_heuristic(last_bsdf_pdf, ip.w) : 1.0f;
+                radiance = radiance + (mk3(ip.x, ip.y, ip.z) * mis) * throughput;
+            }
+            path_done = true;
+        } else {
+            ++closest_hits;
+            hit_state st;
+            fill_hit_state(sc, hr, origin, direction, st);
+            surface si;
+            make_surface(sc, st, si);
+            radiance = radiance + si.emission * throughput;
+            if (st.light >= 0 || depth == p.max_depth) {
+                path_done = true;
+            } else {
+                lobe_mix const lm = make_lobe_mix(st, si, direction);
+                // state.glsl:14-16 - undoes the ray-facing flip, so the offset follows the
+                // mesh's own normal direction even for back-face hits
+                f3 const front_face_normal = st.front_face ? st.normal : -st.normal;
+                f3 const shadow_origin = st.position + front_face_normal * kEpsilon;
+                light_sample ls;
+                bool have_light = propose_light(sc, seed, direction, shadow_origin, ls);
+                if (have_light) {
+                    ++shadow_rays;
+                    have_light = !trace_any<ACCEL, COUNT>(
+                        sc, stk, shadow_origin, ls.wi, ls.shadow_t_max, cnt);
+                }
+                f3 const next_direction = sample_disney(seed, st, si, lm);
+                // One eval_disney body serves both uses (:541-550 and :554-560).
+#pragma nounroll
+                for (int k = have_light ? 0 : 1; k < 2; ++k) {
+                    f3 const l = k == 0 ? ls.wi : next_direction;
+                    f4 const bsdf = eval_disney(st, si, lm, l);
+                    if (k == 0) {
+                        if (bsdf.w > 0.0f) {
+                            bool const is_delta = ls.type == RT_LIGHT_DISTANT;
+                            float const mis = is_delta ? 1.0f : power_heuristic(ls.pdf, bsdf.w);
+                            f3 const f = mk3(bsdf.x, bsdf.y, bsdf.z);
+                            radiance = radiance + (((f * mis) * ls.intensity) / ls.pdf) * throughput;
+                        }
+                    } else {
+                        last_bsdf_pdf = bsdf.w;
+                        if (bsdf.w > 0.0f) {
+                            throughput = throughput * (mk3(bsdf.x, bsdf.y, bsdf.z) / bsdf.w);
+                        } else {
+                            path_done = true;
+                        }
+                    }
+                }
+                direction = next_direction;
+                origin = st.position + next_direction * kEpsilon;
+                ++depth;
+            }
+        }
+        if (path_done) {
+            acc = p.preview ? radiance : acc + radiance;
+            ++pass;
+            if (pass == p.pass_count) {
+                break;
+            }
+            radiance = splat3(0.0f);
+            throughput = splat3(1.0f);
+            depth = 0;
+            primary_ray(p, x, y, pass_seed(p, pass, x, y), seed, origin, direction);
+        }
+    }
+    *reinterpret_cast<float4*>(px) = make_float4(acc.x, acc.y, acc.z, 1.0f);
+
+    if (p.counters) {
+        // one atomic per lane and counter is plenty: this runs once per pixel per launch
+        atomicAdd(&p.counters[0], (unsigned long long) p.pass_count);
+        atomicAdd(&p.counters[1], (unsigned long long) closest_rays);
+        atomicAdd(&p.counters[2], (unsigned long long) shadow_rays);
+        atomicAdd(&p.counters[3], (unsigned long long) closest_hits);
+        if (COUNT) {
+            atomicAdd(&p.counters[4], (unsigned long long) cnt.nodes);
+            atomicAdd(&p.counters[5], (unsigned long long) cnt.tris);
+            atomicMax(&p.counters[6], (unsigned long long) cnt.max_stack);
+        }
+    }
+}
+
+template <int ACCEL>
+__global__ void __launch_bounds__(64) primary_ids_kernel(render_params const p) {
+    __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
+    fast_stack stk;
+    stk.lds = lds_stack + threadIdx.x;
+    uint32_t x, y;
+    if (!lane_pixel(p, x, y)) {
+        return;
+    }
+    uint32_t seed;
+    f3 origin, direction;
+    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, origin, direction);
+    hit_result hr;
+    hr.instance = RT_HIP_MISS;
+    hr.triangle = RT_HIP_MISS;
+    hr.b0 = hr.b1 = hr.b2 = 0.0f;
+    hr.t = kInfinity;
+    trace_counters cnt;
+    bool const hit = trace_closest<ACCEL, false>(p.sc, stk, origin, direction, hr, cnt);
+    size_t const i = (size_t) y * p.frame_width + x;
+    if (p.out_instance) {
+        p.out_instance[i] = hit ? hr.instance : RT_HIP_MISS;
+    }
+    if (p.out_triangle) {
+        p.out_triangle[i] = hit ? hr.triangle : RT_HIP_MISS;
+    }
+    if (p.out_t) {
+        p.out_t[i] = hit ? hr.t : kInfinity;
+    }
+    if (p.out_bary) {
+        p.out_bary[3 * i + 0] = hit ? hr.b0 : 0.0f;
+        p.out_bary[3 * i + 1] = hit ? hr.b1 : 0.0f;
+        p.out_bary[3 * i + 2] = hit ? hr.b2 : 0.0f;
+    }
+}
+
+__global__ void clear_rgba_kernel(float4* img, size_t count) {
+    size_t const i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        img[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    }
+}
+
+thread_local std::string g_last_error;
+
+struct hip_failure : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+void hip_check(hipError_t e, char const* what) {
+    if (e != hipSuccess) {
+        throw hip_failure(std::string{what} + ": " + hipGetErrorString(e));
+    }
+}
+#define HIP_CHECK(expr) hip_check((expr), #expr)
+
+template <typename F>
+int guarded(F&& body) {
+    try {
+        body();
+        return 0;
+    } catch (std::exception const& e) {
+        g_last_error = e.what();
+    } catch (...) {
+        g_last_error = "unknown error";
+    }
+    return 1;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// renderer object
+
+struct rt_hip_renderer {
+    rt_hip_config cfg{};
+    int device = 0;
+    uint32_t tiles_x = 0, tiles_y = 0;
+    uint32_t preview_w = 0, preview_h = 0;
+
+    float* accum = nullptr;
+    float* preview = nullptr;
+    unsigned long long* counters = nullptr;
+
+    std::vector<void*> scene_allocs;
+    scene_dev sc{};
+    bool scene_ready = false;
+
+    uint32_t* seeds = nullptr;
+    size_t seeds_capacity = 0;
+    uint32_t seeds_first_pass = 0, seeds_pass_count = 0;
+
+    uint32_t passes_done = 0;
+    uint32_t tile_cursor = 0;  // tiles dispatched in the current pass (render_tile cadence)
+
+    struct timed_launch {
+        hipEvent_t start, stop;
+    };
+    std::vector<timed_launch> launches;        // not yet folded into the totals
+    std::vector<timed_launch> event_pool;      // reusable events
+    double seconds_total = 0.0;
+    uint32_t launches_total = 0;
+
+    void use_device() const { HIP_CHECK(hipSetDevice(device)); }
+
+    template <typename T>
+    T* upload(T const* host, size_t count) {
+        if (count == 0) {
+            // keep a valid, never-dereferenced pointer
+            count = 1;
+            void* d = nullptr;
+            HIP_CHECK(hipMalloc(&d, sizeof(T)));
+            HIP_CHECK(hipMemset(d, 0, sizeof(T)));
+            scene_allocs.push_back(d);
+            return static_cast<T*>(d);
+        }
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, count * sizeof(T)));
+        scene_allocs.push_back(d);
+        HIP_CHECK(hipMemcpy(d, host, count * sizeof(T), hipMemcpyHostToDevice));
+        return static_cast<T*>(d);
+    }
+
+    void free_scene() {
+        for (void* p : scene_allocs) {
+            (void) hipFree(p);
+        }
+        scene_allocs.clear();
+        scene_ready = false;
+    }
+
+    timed_launch begin_timing(hipStream_t stream) {
+        timed_launch t{};
+        if (!event_pool.empty()) {
+            t = event_pool.back();
+            event_pool.pop_back();
+        } else {
+            HIP_CHECK(hipEventCreate(&t.start));
+            HIP_CHECK(hipEventCreate(&t.stop));
+        }
+        HIP_CHECK(hipEventRecord(t.start, stream));
+        return t;
+    }
+    void end_timing(timed_launch t, hipStream_t stream) {
+        HIP_CHECK(hipEventRecord(t.stop, stream));
+        launches.push_back(t);
+        if (launches.size() >= 256) {
+            fold_timings();
+        }
+    }
+    void fold_timings() {
+        for (timed_launch& t : launches) {
+            HIP_CHECK(hipEventSynchronize(t.stop));
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, t.start, t.stop));
+            seconds_total += (double) ms * 1e-3;
+            ++launches_total;
+            event_pool.push_back(t);
+        }
+        launches.clear();
+    }
+};
+
+namespace {
+
+void validate_scene(rt_scene_desc const& s) {
+    auto need = [](bool ok, char const* what) {
+        if (!ok) {
+            throw std::runtime_error(std::string{"upload_scene: "} + what);
+        }
+    };
+    need(s.tlas && s.tlas_count > 0, "empty TLAS");
+    need(s.blas && s.blas_count > 0, "empty BLAS");
+    need(s.meshes && s.mesh_count > 0, "no meshes");
+    need(s.instances && s.instance_count > 0, "no instances");
+    need(s.triangles && s.triangle_count > 0, "no triangles");
+    need(s.lights && s.light_count > 0,
+        "no lights (the reference host dereferences lights.back() and the shader divides by "
+        "light_count)");
+    need(s.sky_light < (int32_t) s.light_count, "sky_light out of range");
+    need(s.transform_count == 0 || (s.transforms && s.inverse_transforms), "missing transforms");
+    need(s.material_count == 0 || s.materials, "missing materials");
+    need(s.texture_count == 0 || s.textures, "missing textures");
+    // Every index a kernel will follow is checked here, on the host, once.
+    for (uint32_t i = 0; i < s.tlas_count; ++i) {
+        rt_bvh_node const& n = s.tlas[i];
+        if (n.obj_count > 0) {
+            need((uint64_t) n.first_obj + n.obj_count <= s.instance_count, "TLAS leaf out of range");
+        } else {
+            need(i + 1 < s.tlas_count && n.right < s.tlas_count && n.right > i,
+                "TLAS child out of range");
+            need(n.split_axis >= 0 && n.split_axis <= 2, "TLAS split axis");
+        }
+    }
+    for (uint32_t i = 0; i < s.blas_count; ++i) {
+        rt_bvh_node const& n = s.blas[i];
+        if (n.obj_count > 0) {
+            need((uint64_t) n.first_obj + n.obj_count <= s.triangle_count, "BLAS leaf out of range");
+        } else {
+            need(i + 1 < s.blas_count && n.right < s.blas_count && n.right > i,
+                "BLAS child out of range");
+            need(n.split_axis >= 0 && n.split_axis <= 2, "BLAS split axis");
+        }
+    }
+    for (uint32_t i = 0; i < s.mesh_count; ++i) {
+        need(s.meshes[i].bvh_start < s.blas_count, "mesh BLAS root out of range");
+        need(s.meshes[i].triangle_count > 0 &&
+                 (uint64_t) s.meshes[i].triangle_offset + s.meshes[i].triangle_count <=
+                     s.triangle_count,
+            "mesh triangle range");
+    }
+    for (uint32_t i = 0; i < s.instance_count; ++i) {
+        rt_instance const& in = s.instances[i];
+        need(in.mesh < s.mesh_count, "instance mesh");
+        need(in.transform < (int32_t) s.transform_count, "instance transform");
+        need(in.material < (int32_t) s.material_count, "instance material");
+        need(in.light < (int32_t) s.light_count, "instance light");
+    }
+    auto tex_ok = [&](int32_t t) { return t < (int32_t) s.texture_count; };
+    for (uint32_t i = 0; i < s.material_count; ++i) {
+        rt_material const& m = s.materials[i];
+        need(tex_ok(m.albedo_tex) && tex_ok(m.emission_tex) && tex_ok(m.normal_tex) &&
+                 tex_ok(m.metallic_roughness_tex),
+            "material texture index");
+    }
+    for (uint32_t i = 0; i < s.light_count; ++i) {
+        rt_light const& l = s.lights[i];
+        need(tex_ok(l.emission_tex), "light texture index");
+        if (l.type == RT_LIGHT_AREA_SINGLE_SIDED || l.type == RT_LIGHT_AREA_DOUBLE_SIDED) {
+            need(l.mesh < s.mesh_count, "light mesh");
+            need(l.transform < (int32_t) s.transform_count, "light transform");
+        }
+    }
+    for (uint32_t i = 0; i < s.texture_count; ++i) {
+        need(s.textures[i].data && s.textures[i].width > 0 && s.textures[i].height > 0 &&
+                 s.textures[i].format <= RT_TEX_F32X4,
+            "texture");
+    }
+}
+
+uint32_t ref_depth(rt_bvh_node const* nodes, uint32_t root) {
+    uint32_t deepest = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> todo{{root, 1u}};
+    while (!todo.empty()) {
+        auto const [idx, depth] = todo.back();
+        todo.pop_back();
+        deepest = std::max(deepest, depth);
+        if (nodes[idx].obj_count == 0) {
+            todo.push_back({idx + 1, depth + 1});
+            todo.push_back({nodes[idx].right, depth + 1});
+        }
+    }
+    return deepest;
+}
+
+template <typename K>
+void launch_rect(K kernel, render_params const& p, hipStream_t stream) {
+    uint32_t const bx = (p.x1 - p.x0 + 7u) / 8u;
+    uint32_t const by = (p.y1 - p.y0 + 7u) / 8u;
+    hipLaunchKernelGGL(kernel, dim3(bx * by), dim3(64), 0, stream, p);
+    HIP_CHECK(hipGetLastError());
+}
+
+void launch_path_trace(rt_hip_renderer& r, render_params const& p, hipStream_t stream) {
+    bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
+    auto t = r.begin_timing(stream);
+    if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
+        if (count) {
+            launch_rect(path_trace_kernel<RT_HIP_ACCEL_REFERENCE, true>, p, stream);
+        } else {
+            launch_rect(path_trace_kernel<RT_HIP_ACCEL_REFERENCE, false>, p, stream);
+        }
+    } else {
+        if (count) {
+            launch_rect(path_trace_kernel<RT_HIP_ACCEL_REBUILT, true>, p, stream);
+        } else {
+            launch_rect(path_trace_kernel<RT_HIP_ACCEL_REBUILT, false>, p, stream);
+        }
+    }
+    r.end_timing(t, stream);
+}
+
+render_params base_params(rt_hip_renderer const& r, rt_camera const& cam) {
+    render_params p{};
+    p.sc = r.sc;
+    p.cam = cam;
+    p.accum = r.accum;
+    p.frame_width = r.cfg.width;
+    p.x0 = 0;
+    p.y0 = 0;
+    p.x1 = r.cfg.width;
+    p.y1 = r.cfg.height;
+    p.tile_width = r.cfg.tile_width;
+    p.tile_height = r.cfg.tile_height;
+    p.tiles_x = r.tiles_x;
+    p.tile_count = r.tiles_x * r.tiles_y;
+    p.pass_count = 1;
+    p.max_depth = r.cfg.max_depth;
+    p.counters = r.counters;
+    return p;
+}
+
+void require_scene(rt_hip_renderer const* r) {
+    if (!r) {
+        throw std::runtime_error("null renderer");
+    }
+    if (!r->scene_ready) {
+        throw std::runtime_error("no scene uploaded");
+    }
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// C ABI
+
+extern "C" {
+
+int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
+    return guarded([&] {
+        if (!config || !out) {
+            throw std::runtime_error("create: null argument");
+        }
+        rt_hip_config const& c = *config;
+        if (c.width == 0 || c.height == 0 || c.tile_width == 0 || c.tile_height == 0) {
+            throw std::runtime_error("create: zero-sized frame or tile");
+        }
+        if (c.width % c.tile_width != 0) {
+            throw std::runtime_error("Window width isn't divisible by tile width");
+        }
+        if (c.height % c.tile_height != 0) {
+            throw std::runtime_error("Window height isn't divisible by tile height");
+        }
+        if (c.accel > RT_HIP_ACCEL_REBUILT) {
+            throw std::runtime_error("create: unknown accel mode");
+        }
+        int device_count = 0;
+        HIP_CHECK(hipGetDeviceCount(&device_count));
+        if (device_count == 0) {
+            throw std::runtime_error("create: no HIP device is visible");
+        }
+        auto r = std::make_unique<rt_hip_renderer>();
+        r->cfg = c;
+        if (c.device >= 0) {
+            r->device = c.device;
+        } else {
+            HIP_CHECK(hipGetDevice(&r->device));
+        }
+        if (r->device >= device_count) {
+            throw std::runtime_error("create: device ordinal out of range");
+        }
+        r->use_device();
+        r->tiles_x = c.width / c.tile_width;
+        r->tiles_y = c.height / c.tile_height;
+        r->preview_w = std::max(1u, c.width / kPreviewRatio);
+        r->preview_h = std::max(1u, c.height / kPreviewRatio);
+        size_t const accum_bytes = (size_t) c.width * c.height * 4 * sizeof(float);
+        size_t const preview_bytes = (size_t) r->preview_w * r->preview_h * 4 * sizeof(float);
+        HIP_CHECK(hipMalloc((void**) &r->accum, accum_bytes));
+        HIP_CHECK(hipMalloc((void**) &r->preview, preview_bytes));
+        HIP_CHECK(hipMalloc((void**) &r->counters, kCounterWords * sizeof(unsigned long long)));
+        HIP_CHECK(hipMemset(r->accum, 0, accum_bytes));
+        HIP_CHECK(hipMemset(r->preview, 0, preview_bytes));
+        HIP_CHECK(hipMemset(r->counters, 0, kCounterWords * sizeof(unsigned long long)));
+        *out = r.release();
+    });
+}
+
+int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
+    return guarded([&] {
+        if (!r || !scene) {
+            throw std::runtime_error("upload_scene: null argument");
+        }
+        validate_scene(*scene);
+        rt_scene_desc const& s = *scene;
+        r->use_device();
+        HIP_CHECK(hipDeviceSynchronize());
+        r->free_scene();
+        scene_dev d{};
+        d.tlas = r->upload(s.tlas, s.tlas_count);
+        d.blas = r->upload(s.blas, s.blas_count);
+        d.meshes = r->upload(s.meshes, s.mesh_count);
+        d.instances = r->upload(s.instances, s.instance_count);
+        d.triangles = r->upload(s.triangles, s.triangle_count);
+        d.transforms = r->upload(s.transforms, s.transform_count);
+        d.inverse_transforms = r->upload(s.inverse_transforms, s.transform_count);
+        d.materials = r->upload(s.materials, s.material_count);
+        d.lights = r->upload(s.lights, s.light_count);
+        std::vector<texture_dev> textures(s.texture_count);
+        for (uint32_t i = 0; i < s.texture_count; ++i) {
+            rt_texture const& t = s.textures[i];
+            size_t const texel = t.format == RT_TEX_F32X4 ? 16 : 4;
+            textures[i].data = r->upload(
+                static_cast<const uint8_t*>(t.data), (size_t) t.width * t.height * texel);
+            textures[i].width = t.width;
+            textures[i].height = t.height;
+            textures[i].format = t.format;
+        }
+        d.textures = r->upload(textures.data(), textures.size());
+        d.light_count = s.light_count;
+        d.sky_light = s.sky_light;
+        if (r->cfg.accel == RT_HIP_ACCEL_REFERENCE) {
+            uint32_t blas_depth = 0;
+            for (uint32_t m = 0; m < s.mesh_count; ++m) {
+                blas_depth = std::max(blas_depth, ref_depth(s.blas, s.meshes[m].bvh_start));
+            }
+            uint32_t const need = ref_depth(s.tlas, 0) + blas_depth;
+            if (need > kRefStackCapacity) {
+                throw std::runtime_error("upload_scene: the uploaded BVH is " +
+                                         std::to_string(need) +
+                                         " levels deep; reference-order traversal supports " +
+                                         std::to_string(kRefStackCapacity));
+            }
+        } else {
+            built_accel const accel = build_wide_accel(s);
+            if (accel.max_stack_bound > kFastLdsEntries + kFastSpillEntries) {
+                throw std::runtime_error("upload_scene: rebuilt BVH exceeds the traversal stack");
+            }
+            d.wide_nodes = r->upload(accel.nodes.data(), accel.nodes.size());
+            d.wide_tris = r->upload(accel.tris.data(), accel.tris.size());
+            d.wide_instances = r->upload(accel.instances.data(), accel.instances.size());
+            d.wide_tlas_root = accel.tlas_root;
+        }
+        r->sc = d;
+        r->scene_ready = true;
+    });
+}
+
+int rt_hip_upload_seeds(rt_hip_renderer* r, const uint32_t* seeds, uint32_t first_pass,
+    uint32_t pass_count) {
+    return guarded([&] {
+        if (!r || !seeds || pass_count == 0) {
+            throw std::runtime_error("upload_seeds: null or empty argument");
+        }
+        r->use_device();
+        size_t const words = (size_t) pass_count * r->tiles_x * r->tiles_y;
+        HIP_CHECK(hipDeviceSynchronize());
+        if (words > r->seeds_capacity) {
+            if (r->seeds) {
+                HIP_CHECK(hipFree(r->seeds));
+                r->seeds = nullptr;
+                r->seeds_capacity = 0;
+            }
+            HIP_CHECK(hipMalloc((void**) &r->seeds, words * sizeof(uint32_t)));
+            r->seeds_capacity = words;
+        }
+        HIP_CHECK(hipMemcpy(r->seeds, seeds, words * sizeof(uint32_t), hipMemcpyHostToDevice));
+        r->seeds_first_pass = first_pass;
+        r->seeds_pass_count = pass_count;
+    });
+}
+
+int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream) {
+    return guarded([&] {
+        if (!r) {
+            throw std::runtime_error("null renderer");
+        }
+        r->use_device();
+        size_t const pixels = (size_t) r->cfg.width * r->cfg.height;
+        float* target = accum_dev ? accum_dev : r->accum;
+        hipLaunchKernelGGL(clear_rgba_kernel, dim3((uint32_t) ((pixels + 255) / 256)), dim3(256),
+            0, (hipStream_t) stream, reinterpret_cast<float4*>(target), pixels);
+        HIP_CHECK(hipGetLastError());
+        if (!accum_dev) {
+            r->passes_done = 0;
+            r->tile_cursor = 0;
+        }
+    });
+}
+
+int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
+    uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream) {
+    return guarded([&] {
+        require_scene(r);
+        if (!camera) {
+            throw std::runtime_error("render: null camera");
+        }
+        if (pass_count == 0) {
+            return;
+        }
+        if (!r->seeds || first_pass < r->seeds_first_pass ||
+            (uint64_t) first_pass + pass_count >
+                (uint64_t) r->seeds_first_pass + r->seeds_pass_count) {
+            throw std::runtime_error("render: seeds for the requested passes are not resident");
+        }
+        r->use_device();
+        render_params p = base_params(*r, *camera);
+        if (rect) {
+            if (rect[0] >= rect[2] || rect[1] >= rect[3] || rect[2] > r->cfg.width ||
+                rect[3] > r->cfg.height) {
+                throw std::runtime_error("render: bad rectangle");
+            }
+            p.x0 = rect[0];
+            p.y0 = rect[1];
+            p.x1 = rect[2];
+            p.y1 = rect[3];
+        }
+        if (accum_dev) {
+            p.accum = accum_dev;
+        }
+        p.pass_count = pass_count;
+        p.seeds = r->seeds + (size_t) (first_pass - r->seeds_first_pass) * p.tile_count;
+        launch_path_trace(*r, p, (hipStream_t) stream);
+        if (!accum_dev && !rect) {
+            r->passes_done += pass_count;
+        }
+    });
+}
+
+int rt_hip_render_tile(rt_hip_renderer* r, const rt_camera* camera, uint32_t random_seed,
+    uint32_t tile_x, uint32_t tile_y, void* stream) {
+    return guarded([&] {
+        require_scene(r);
+        if (!camera) {
+            throw std::runtime_error("render_tile: null camera");
+        }
+        if (tile_x >= r->tiles_x || tile_y >= r->tiles_y) {
+            throw std::runtime_error("render_tile: tile index out of range");
+        }
+        r->use_device();
+        render_params p = base_params(*r, *camera);
+        p.x0 = tile_x * r->cfg.tile_width;
+        p.y0 = tile_y * r->cfg.tile_height;
+        p.x1 = p.x0 + r->cfg.tile_width;
+        p.y1 = p.y0 + r->cfg.tile_height;
+        p.seeds = nullptr;
+        p.scalar_seed = random_seed;
+        launch_path_trace(*r, p, (hipStream_t) stream);
+        if (++r->tile_cursor == r->tiles_x * r->tiles_y) {
+            r->tile_cursor = 0;
+            ++r->passes_done;
+        }
+    });
+}
+
+int rt_hip_render_preview(rt_hip_renderer* r, const rt_camera* preview_camera,
+    uint32_t random_seed, void* stream) {
+    return guarded([&] {
+        require_scene(r);
+        if (!preview_camera) {
+            throw std::runtime_error("render_preview: null camera");
+        }
+        r->use_device();
+        render_params p = base_params(*r, *preview_camera);
+        p.accum = r->preview;
+        p.frame_width = r->preview_w;
+        p.x1 = r->preview_w;
+        p.y1 = r->preview_h;
+        p.preview = 1;
+        p.seeds = nullptr;
+        p.scalar_seed = random_seed;
+        launch_path_trace(*r, p, (hipStream_t) stream);
+        r->passes_done = 0;
+        r->tile_cursor = 0;
+    });
+}
+
+int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pass,
+    uint32_t* instance_ids, uint32_t* triangle_ids, float* hit_t, float* bary) {
+    return guarded([&] {
+        require_scene(r);
+        if (!camera) {
+            throw std::runtime_error("primary_ids: null camera");
+        }
+        if (!r->seeds || pass < r->seeds_first_pass ||
+            pass >= r->seeds_first_pass + r->seeds_pass_count) {
+            throw std::runtime_error("primary_ids: seeds for that pass are not resident");
+        }
+        r->use_device();
+        size_t const pixels = (size_t) r->cfg.width * r->cfg.height;
+        render_params p = base_params(*r, *camera);
+        p.seeds = r->seeds + (size_t) (pass - r->seeds_first_pass) * p.tile_count;
+        p.counters = nullptr;
+        std::vector<void*> temps;
+        auto temp = [&](size_t bytes) {
+            void* d = nullptr;
+            HIP_CHECK(hipMalloc(&d, bytes));
+            temps.push_back(d);
+            return d;
+        };
+        try {
+            p.out_instance = instance_ids ? (uint32_t*) temp(pixels * 4) : nullptr;
+            p.out_triangle = triangle_ids ? (uint32_t*) temp(pixels * 4) : nullptr;
+            p.out_t = hit_t ? (float*) temp(pixels * 4) : nullptr;
+            p.out_bary = bary ? (float*) temp(pixels * 12) : nullptr;
+            if (r->cfg.accel == RT_HIP_ACCEL_REFERENCE) {
+                launch_rect(primary_ids_kernel<RT_HIP_ACCEL_REFERENCE>, p, nullptr);
+            } else {
+                launch_rect(primary_ids_kernel<RT_HIP_ACCEL_REBUILT>, p, nullptr);
+            }
+            HIP_CHECK(hipDeviceSynchronize());
+            if (instance_ids) {
+                HIP_CHECK(hipMemcpy(instance_ids, p.out_instance, pixels * 4, hipMemcpyDeviceToHost));
+            }
+            if (triangle_ids) {
+                HIP_CHECK(hipMemcpy(triangle_ids, p.out_triangle, pixels * 4, hipMemcpyDeviceToHost));
+            }
+            if (hit_t) {
+                HIP_CHECK(hipMemcpy(hit_t, p.out_t, pixels * 4, hipMemcpyDeviceToHost));
+            }
+            if (bary) {
+                HIP_CHECK(hipMemcpy(bary, p.out_bary, pixels * 12, hipMemcpyDeviceToHost));
+            }
+        } catch (...) {
+            for (void* d : temps) {
+                (void) hipFree(d);
+            }
+            throw;
+        }
+        for (void* d : temps) {
+            (void) hipFree(d);
+        }
+    });
+}
+
+int rt_hip_read_accum(rt_hip_renderer* r, float* rgba, uint32_t* passes, void* stream) {
+    return guarded([&] {
+        if (!r || !rgba) {
+            throw std::runtime_error("read_accum: null argument");
+        }
+        r->use_device();
+        HIP_CHECK(hipStreamSynchronize((hipStream_t) stream));
+        HIP_CHECK(hipMemcpy(rgba, r->accum, (size_t) r->cfg.width * r->cfg.height * 16,
+            hipMemcpyDeviceToHost));
+        if (passes) {
+            *passes = r->passes_done;
+        }
+    });
+}
+
+int rt_hip_read_preview(rt_hip_renderer* r, float* rgba, void* stream) {
+    return guarded([&] {
+        if (!r || !rgba) {
+            throw std::runtime_error("read_preview: null argument");
+        }
+        r->use_device();
+        HIP_CHECK(hipStreamSynchronize((hipStream_t) stream));
+        HIP_CHECK(hipMemcpy(rgba, r->preview, (size_t) r->preview_w * r->preview_h * 16,
+            hipMemcpyDeviceToHost));
+    });
+}
+
+int rt_hip_accum_ptr(rt_hip_renderer* r, void** accum_dev) {
+    return guarded([&] {
+        if (!r || !accum_dev) {
+            throw std::runtime_error("accum_ptr: null argument");
+        }
+        *accum_dev = r->accum;
+    });
+}
+
+int rt_hip_set_passes(rt_hip_renderer* r, uint32_t passes) {
+    return guarded([&] {
+        if (!r) {
+            throw std::runtime_error("null renderer");
+        }
+        r->passes_done = passes;
+    });
+}
+
+int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
+    return guarded([&] {
+        if (!r) {
+            throw std::runtime_error("null renderer");
+        }
+        r->use_device();
+        HIP_CHECK(hipDeviceSynchronize());
+        r->fold_timings();
+        unsigned long long words[kCounterWords];
+        HIP_CHECK(hipMemcpy(words, r->counters, sizeof(words), hipMemcpyDeviceToHost));
+        if (out) {
+            out->samples = words[0];
+            out->closest_rays = words[1];
+            out->shadow_rays = words[2];
+            out->closest_hits = words[3];
+            out->nodes_visited = words[4];
+            out->tris_tested = words[5];
+            out->max_stack = words[6];
+            out->seconds = r->seconds_total;
+        }
+        if (reset) {
+            HIP_CHECK(hipMemset(r->counters, 0, sizeof(words)));
+            r->seconds_total = 0.0;
+            r->launches_total = 0;
+        }
+    });
+}
+
+int rt_hip_kernel_time(rt_hip_renderer* r, double* avg_ms, uint32_t* launches) {
+    return guarded([&] {
+        if (!r) {
+            throw std::runtime_error("null renderer");
+        }
+        r->use_device();
+        r->fold_timings();
+        if (avg_ms) {
+            *avg_ms = r->launches_total ? r->seconds_total * 1e3 / r->launches_total : 0.0;
+        }
+        if (launches) {
+            *launches = r->launches_total;
+        }
+    });
+}
+
+int rt_hip_destroy(rt_hip_renderer* r) {
+    return guarded([&] {
+        if (!r) {
+            return;
+        }
+        (void) hipSetDevice(r->device);
+        (void) hipDeviceSynchronize();
+        r->free_scene();
+        for (auto& t : r->launches) {
+            (void) hipEventDestroy(t.start);
+            (void) hipEventDestroy(t.stop);
+        }
+        for (auto& t : r->event_pool) {
+            (void) hipEventDestroy(t.start);
+            (void) hipEventDestroy(t.stop);
+        }
+        (void) hipFree(r->accum);
+        (void) hipFree(r->preview);
+        (void) hipFree(r->counters);
+        (void) hipFree(r->seeds);
+        delete r;
+    });
+}
+
+const char* rt_hip_last_error(void) {
+    return g_last_error.c_str();
+}
+
+}  // extern "C"

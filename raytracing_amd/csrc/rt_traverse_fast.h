@@ -1,0 +1,186 @@
+// Traversal of the rebuilt acceleration structure (RT_HIP_ACCEL_REBUILT).
+//
+// Layout choices for gfx950 (no ray-tracing hardware, 64-wide waves, one ray
+// per lane):
+//   * 64-byte nodes that carry BOTH children's boxes: one aligned 64-byte
+//     fetch (four dwordx4 loads) decides a whole step, instead of two
+//     dependent 40-byte fetches that straddle cache lines;
+//   * a positions-only 48-byte triangle stream in leaf order (the reference
+//     fetches 96 bytes, 60 of them normals/uvs, for every tested triangle);
+//   * TLAS and BLAS walked in ONE loop with one stack: entering an instance
+//     pushes a marker and switches the ray to object space, popping the
+//     marker switches back, so the wave never re-converges per instance;
+//   * the traversal stack lives in LDS (stack[entry][lane]: conflict-free for
+//     a wave), with a private overflow area that is essentially never used;
+//   * nearer child first by entry distance; the farther child is pushed and
+//     its own children are tested against the then-current t_max when popped.
+//
+// The triangle test is the reference's arithmetic unchanged (hit_triangle),
+// applied to the same object-space ray, so t and the barycentrics of a given
+// (instance, triangle) pair are bit-identical to the reference-order walk.
+// Box tests use one fma per plane and are widened by 2 ulp so that rounding
+// can only add candidates, never lose the true closest hit.
+#pragma once
+
+#include "rt_traverse_ref.h"
+
+namespace rtd {
+
+constexpr uint32_t kFastLdsEntries = 32;   // per-lane LDS stack entries
+constexpr uint32_t kFastSpillEntries = 64; // private overflow entries
+constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
+
+struct fast_stack {
+    uint32_t* lds;  // this lane's column: entry e at lds[e * 64]
+};
+
+struct slab_ray {
+    f3 inv;   // 1 / direction
+    f3 oinv;  // -origin * inv   (t = plane * inv + oinv)
+};
+
+RT_DEV slab_ray make_slab_ray(f3 o, f3 d) {
+    slab_ray r;
+    r.inv = splat3(1.0f) / d;
+    r.oinv = mk3(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
+    return r;
+}
+
+// Entry/exit distances of one box.  NaNs from 0*inf drop out of fmin/fmax.
+RT_DEV void slab_box(slab_ray const& r, float lox, float loy, float loz, float hix, float hiy,
+    float hiz, float t_max, float& t_enter, float& t_exit) {
+    float const ax = __builtin_fmaf(lox, r.inv.x, r.oinv.x);
+    float const bx = __builtin_fmaf(hix, r.inv.x, r.oinv.x);
+    float const ay = __builtin_fmaf(loy, r.inv.y, r.oinv.y);
+    float const by = __builtin_fmaf(hiy, r.inv.y, r.oinv.y);
+    float const az = __builtin_fmaf(loz, r.inv.z, r.oinv.z);
+    float const bz = __builtin_fmaf(hiz, r.inv.z, r.oinv.z);
+    float const nx = fminf(ax, bx), fx = fmaxf(ax, bx);
+    float const ny = fminf(ay, by), fy = fmaxf(ay, by);
+    float const nz = fminf(az, bz), fz = fmaxf(az, bz);
+    t_enter = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f)) * 0.99999976f;
+    t_exit = fminf(fminf(fx, fy), fminf(fz, t_max)) * 1.0000002f;
+}
+
+template <bool ANY, bool COUNT>
+RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, f3 origin, f3 direction,
+    float t_limit, hit_result& best, trace_counters& cnt) {
+    uint32_t spill[kFastSpillEntries];
+    uint32_t sp = 0;
+    auto push = [&](int32_t v) {
+        if (sp < kFastLdsEntries) {
+            stk.lds[sp * 64u] = (uint32_t) v;
+        } else if (sp - kFastLdsEntries < kFastSpillEntries) {
+            spill[sp - kFastLdsEntries] = (uint32_t) v;
+        }
+        ++sp;
+        if (COUNT) {
+            cnt.max_stack = max(cnt.max_stack, sp);
+        }
+    };
+    auto pop = [&]() -> int32_t {
+        --sp;
+        if (sp < kFastLdsEntries) {
+            return (int32_t) stk.lds[sp * 64u];
+        }
+        uint32_t const i = sp - kFastLdsEntries;
+        return (int32_t) spill[i < kFastSpillEntries ? i : 0];
+    };
+
+    float t_max = t_limit;
+    bool found = false;
+    slab_ray const world_slab = make_slab_ray(origin, direction);
+    slab_ray slab = world_slab;
+    tri_ray tr = make_tri_ray(origin, direction);
+    uint32_t current_instance = 0;
+    int32_t cur = sc.wide_tlas_root;
+    bool in_blas = false;
+
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+            float4 const n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            if (COUNT) {
+                ++cnt.nodes;
+            }
+            float e0, x0, e1, x1;
+            slab_box(slab, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, t_max, e0, x0);
+            slab_box(slab, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, t_max, e1, x1);
+            bool const h0 = e0 <= x0;
+            bool const h1 = e1 <= x1;
+            int32_t const c0 = __float_as_int(n3.x);
+            int32_t const c1 = __float_as_int(n3.y);
+            if (h0 && h1) {
+                bool const first0 = e0 <= e1;
+                push(first0 ? c1 : c0);
+                cur = first0 ? c0 : c1;
+                continue;
+            }
+            if (h0 || h1) {
+                cur = h0 ? c0 : c1;
+                continue;
+            }
+        } else if (!in_blas) {
+            // TLAS leaf: exactly one instance.  Enter its BLAS.
+            uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
+            const float4* rp = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+            float4 const r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
+            f3 o, d;
+            o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
+            o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
+            o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
+            d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
+            d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
+            d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
+            slab = make_slab_ray(o, d);
+            tr = make_tri_ray(o, d);
+            current_instance = (uint32_t) __float_as_int(r3.y);
+            push(kInstanceMarker);
+            in_blas = true;
+            cur = __float_as_int(r3.x);
+            continue;
+        } else {
+            // BLAS leaf: 1..8 triangles.
+            uint32_t const code = (uint32_t) ~cur;
+            uint32_t const first = code >> 3;
+            uint32_t const count = (code & 7u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+                float4 const va = tp[0], vb = tp[1], vc = tp[2];
+                if (COUNT) {
+                    ++cnt.tris;
+                }
+                float b0, b1, b2, th;
+                if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
+                        mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th)) {
+                    if (ANY) {
+                        return true;
+                    }
+                    t_max = th;
+                    found = true;
+                    best.instance = current_instance;
+                    best.triangle = (uint32_t) __float_as_int(va.w);
+                    best.b0 = b0;
+                    best.b1 = b1;
+                    best.b2 = b2;
+                    best.t = th;
+                }
+            }
+        }
+        // pop the next subtree
+        for (;;) {
+            if (sp == 0) {
+                return found;
+            }
+            cur = pop();
+            if (cur != kInstanceMarker) {
+                break;
+            }
+            in_blas = false;
+            slab = world_slab;
+        }
+    }
+}
+
+}  // namespace rtd

@@ -81,7 +81,8 @@ class SceneDesc(C.Structure):
 
 class Stats(C.Structure):
     _fields_ = [("samples", C.c_uint64), ("closest_rays", C.c_uint64),
-                ("shadow_rays", C.c_uint64), ("nodes_visited", C.c_uint64),
+                ("shadow_rays", C.c_uint64), ("closest_hits", C.c_uint64),
+                ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("max_stack", C.c_uint64),
                 ("seconds", C.c_double)]
 
@@ -99,7 +100,7 @@ class HostInfo(C.Structure):
 
 _EXPECTED_SIZES = {BvhNode: 40, Mesh: 12, Instance: 20, Vertex: 32, Triangle: 96, Mat4: 64,
                    Material: 96, Medium: 32, Light: 48, Texture: 24, Camera: 48,
-                   SceneDesc: 11 * 8 + 12 * 4, Stats: 56}
+                   SceneDesc: 11 * 8 + 12 * 4, Stats: 64}
 for _cls, _size in _EXPECTED_SIZES.items():
     assert C.sizeof(_cls) == _size, (_cls.__name__, C.sizeof(_cls), _size)
 

@@ -1,0 +1,165 @@
+"""Python access to librt_hip.so (the gfx950 path tracer) through its C ABI.
+
+There is no CPU fallback: if the library is missing, or no GPU is visible, calls raise.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import ctypes_defs as T
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_hip.so")
+_lib = None
+
+ACCEL_REFERENCE = 0
+ACCEL_REBUILT = 1
+FLAG_COUNT_NODES = 1
+MISS = 0xFFFFFFFF
+
+EXPORTS = [
+    "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
+    "rt_hip_render", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
+    "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_set_passes",
+    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_destroy", "rt_hip_last_error",
+]
+
+
+class Config(C.Structure):
+    _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32),
+                ("tile_width", C.c_uint32), ("tile_height", C.c_uint32), ("device", C.c_int32),
+                ("accel", C.c_uint32), ("flags", C.c_uint32)]
+
+
+fp = C.POINTER(C.c_float)
+u32p = C.POINTER(C.c_uint32)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"{_LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+        try:
+            # PyTorch ships its own libamdhip64 under the same SONAME as /opt/rocm's.  Loading
+            # torch first makes the process use ONE HIP runtime, so torch streams and tensors
+            # can be handed to this library.
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+        l = C.CDLL(_LIB_PATH)
+        l.rt_hip_last_error.restype = C.c_char_p
+        l.rt_hip_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+        l.rt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
+        l.rt_hip_upload_seeds.argtypes = [C.c_void_p, u32p, C.c_uint32, C.c_uint32]
+        l.rt_hip_clear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        l.rt_hip_render.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
+                                    u32p, C.c_void_p, C.c_void_p]
+        l.rt_hip_render_tile.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
+                                         C.c_uint32, C.c_void_p]
+        l.rt_hip_render_preview.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32,
+                                            C.c_void_p]
+        l.rt_hip_primary_ids.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, u32p, u32p,
+                                         fp, fp]
+        l.rt_hip_read_accum.argtypes = [C.c_void_p, fp, u32p, C.c_void_p]
+        l.rt_hip_read_preview.argtypes = [C.c_void_p, fp, C.c_void_p]
+        l.rt_hip_accum_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.rt_hip_set_passes.argtypes = [C.c_void_p, C.c_uint32]
+        l.rt_hip_stats.argtypes = [C.c_void_p, C.POINTER(T.Stats), C.c_int]
+        l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
+        l.rt_hip_destroy.argtypes = [C.c_void_p]
+        _lib = l
+    return _lib
+
+
+def _check(code):
+    if code != 0:
+        raise RuntimeError(lib().rt_hip_last_error().decode())
+
+
+class HipRenderer:
+    """One renderer handle on one GPU.  Mirrors the C ABI one to one."""
+
+    def __init__(self, width, height, max_depth, tile, device=-1, accel=ACCEL_REBUILT, flags=0):
+        cfg = Config(width, height, max_depth, tile[0], tile[1], device, accel, flags)
+        self.width, self.height, self.max_depth, self.tile = width, height, max_depth, tuple(tile)
+        self.tile_count = (width // tile[0]) * (height // tile[1])
+        self._h = C.c_void_p()
+        _check(lib().rt_hip_create(C.byref(cfg), C.byref(self._h)))
+
+    def upload_scene(self, desc):
+        _check(lib().rt_hip_upload_scene(self._h, C.byref(desc)))
+
+    def upload_seeds(self, seeds, first_pass=0):
+        seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
+        assert seeds.ndim == 2 and seeds.shape[1] == self.tile_count, seeds.shape
+        _check(lib().rt_hip_upload_seeds(self._h, seeds.ctypes.data_as(u32p), first_pass,
+                                         seeds.shape[0]))
+
+    def clear(self, accum_dev=None, stream=None):
+        _check(lib().rt_hip_clear(self._h, accum_dev, stream))
+
+    def render(self, camera, first_pass, pass_count, rect=None, accum_dev=None, stream=None):
+        r = (C.c_uint32 * 4)(*rect) if rect is not None else None
+        _check(lib().rt_hip_render(self._h, C.byref(camera), first_pass, pass_count, r,
+                                   accum_dev, stream))
+
+    def render_tile(self, camera, random_seed, tile_x, tile_y, stream=None):
+        _check(lib().rt_hip_render_tile(self._h, C.byref(camera), random_seed, tile_x, tile_y,
+                                        stream))
+
+    def render_preview(self, preview_camera, random_seed, stream=None):
+        _check(lib().rt_hip_render_preview(self._h, C.byref(preview_camera), random_seed, stream))
+
+    def primary_ids(self, camera, pass_index=0):
+        n = (self.height, self.width)
+        inst = np.empty(n, dtype=np.uint32)
+        tri = np.empty(n, dtype=np.uint32)
+        t = np.empty(n, dtype=np.float32)
+        bary = np.empty(n + (3,), dtype=np.float32)
+        _check(lib().rt_hip_primary_ids(self._h, C.byref(camera), pass_index,
+                                        inst.ctypes.data_as(u32p), tri.ctypes.data_as(u32p),
+                                        t.ctypes.data_as(fp), bary.ctypes.data_as(fp)))
+        return inst, tri, t, bary
+
+    def read_accum(self, stream=None):
+        out = np.empty((self.height, self.width, 4), dtype=np.float32)
+        passes = C.c_uint32()
+        _check(lib().rt_hip_read_accum(self._h, out.ctypes.data_as(fp), C.byref(passes), stream))
+        return out, passes.value
+
+    def read_preview(self, stream=None):
+        out = np.empty((max(1, self.height // 10), max(1, self.width // 10), 4), dtype=np.float32)
+        _check(lib().rt_hip_read_preview(self._h, out.ctypes.data_as(fp), stream))
+        return out
+
+    def accum_ptr(self):
+        p = C.c_void_p()
+        _check(lib().rt_hip_accum_ptr(self._h, C.byref(p)))
+        return p.value
+
+    def set_passes(self, passes):
+        _check(lib().rt_hip_set_passes(self._h, passes))
+
+    def stats(self, reset=False):
+        s = T.Stats()
+        _check(lib().rt_hip_stats(self._h, C.byref(s), 1 if reset else 0))
+        return s.as_dict()
+
+    def kernel_time(self):
+        ms = C.c_double()
+        n = C.c_uint32()
+        _check(lib().rt_hip_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self._h:
+            lib().rt_hip_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

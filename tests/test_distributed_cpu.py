@@ -1,0 +1,90 @@
+"""Multi-GPU split logic on CPU: pass partition, and a world_size-2 `gloo` run in which each
+rank renders its pass range (with the CPU oracle standing in for the GPU kernel) and the
+accumulators are reduced exactly as bench.py and the renderer do it on RCCL."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from raytracing_amd import distributed as rd
+
+from conftest import ROOT
+
+
+def test_pass_range_partitions_exactly():
+    for total in (0, 1, 7, 64, 1024, 4096):
+        for world in (1, 2, 3, 4, 8):
+            covered = []
+            for rank in range(world):
+                first, count = rd.pass_range(total, world, rank)
+                covered += list(range(first, first + count))
+                assert count in (total // world, total // world + 1)
+            assert covered == list(range(total))
+    with pytest.raises(ValueError):
+        rd.pass_range(8, 2, 2)
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, total_passes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from raytracing_amd import host, scenes
+    sc = scenes.load_snapshot("cornell_box")
+    w, h, tile, md = 64, 64, (16, 16), 4
+    cam = sc.camera(w, h)
+    tiles = 16
+
+    def render_passes(first, count, accum):
+        seeds = host.seed_schedule(first, count, tiles)   # GLOBAL pass indices
+        buf = accum.numpy()
+        oracle.render(sc.desc, cam, w, h, md, tile, seeds, accum=buf, first_pass=first,
+                      threads=2)
+
+    accum = rd.new_accumulator(h, w, "cpu")
+    first, count = rd.render_distributed(render_passes, total_passes, accum)
+    np.save(os.path.join(out_dir, f"range_{rank}.npy"), np.array([first, count]))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "reduced.npy"), accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_render_equals_single_rank(tmp_path, cornell):
+    import oracle
+    from raytracing_amd import host
+    total = 6
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, total, str(tmp_path)), nprocs=2, join=True)
+    ranges = [tuple(np.load(tmp_path / f"range_{r}.npy")) for r in range(2)]
+    assert ranges == [(0, 3), (3, 3)]
+    reduced = np.load(tmp_path / "reduced.npy")
+    w, h, tile, md = 64, 64, (16, 16), 4
+    seeds = host.seed_schedule(0, total, 16)
+    single, _ = oracle.render(cornell.desc, cornell.camera(w, h), w, h, md, tile, seeds)
+    assert (reduced[..., 3] == 1.0).all()
+    # same samples, different association of the float sum: (a+b+c) + (d+e+f) vs a+b+...+f
+    assert np.allclose(reduced, single, rtol=2e-6, atol=1e-6)
+    # and the two halves really are different work: one half alone is not the whole
+    half, _ = oracle.render(cornell.desc, cornell.camera(w, h), w, h, md, tile, seeds[:3])
+    assert not np.allclose(half, single, rtol=1e-3, atol=1e-3)
+
+
+def test_reduce_is_identity_without_a_process_group():
+    accum = rd.new_accumulator(4, 4, "cpu")
+    accum[..., :3] = 2.0
+    out = rd.reduce_accumulator(accum)
+    assert out is accum and (accum[..., :3] == 2.0).all() and (accum[..., 3] == 1.0).all()

@@ -1,0 +1,237 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle on the same seeds.
+
+Bars:
+  * primary-hit instance / triangle ids, t and barycentrics: bit-exact in the
+    reference-order mode; in the rebuilt-BVH mode identical except at documented ties or
+    grazing box tests, each of which is checked to be a tie (same t within 4 ulp);
+  * ray counts: identical, or within a few paths when a transcendental differs by an ulp
+    between libm and the device library and flips a branch;
+  * images (float32): per value |gpu - oracle| <= 1e-3 * |oracle| + 1e-4 for all but a
+    fraction 2e-3 of the values (a flipped branch changes a whole path), and a relative
+    RMSE over the image <= 2e-3.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch  # noqa: F401  (first, so one ROCm runtime is shared)
+
+import oracle
+from raytracing_amd import hip, host
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+ACCELS = [hip.ACCEL_REFERENCE, hip.ACCEL_REBUILT]
+REL_TOL, ABS_TOL, BAD_FRACTION, REL_RMSE = 1e-3, 1e-4, 2e-3, 2e-3
+
+
+def make_renderer(sc, w, h, md, tile, accel, flags=0):
+    r = hip.HipRenderer(w, h, md, tile, accel=accel, flags=flags)
+    r.upload_scene(sc.desc)
+    return r
+
+
+def assert_image_close(got, want, what=""):
+    assert np.isfinite(got).all(), what
+    err = np.abs(got[..., :3] - want[..., :3])
+    tol = REL_TOL * np.abs(want[..., :3]) + ABS_TOL
+    bad = float((err > tol).mean())
+    rmse = float(np.sqrt((err ** 2).mean()) / (np.sqrt((want[..., :3] ** 2).mean()) + 1e-12))
+    assert bad <= BAD_FRACTION, f"{what}: {bad:.5f} of the values outside tolerance"
+    assert rmse <= REL_RMSE, f"{what}: relative RMSE {rmse:.3g}"
+    assert (got[..., 3] == 1.0).all()
+
+
+def ulp_distance(a, b):
+    ai = a.view(np.int32).astype(np.int64)
+    bi = b.view(np.int32).astype(np.int64)
+    return np.abs(ai - bi)
+
+
+def check_ids(sc, w, h, tile, accel):
+    cam = sc.camera(w, h)
+    seeds = host.seed_schedule(0, 1, (w // tile[0]) * (h // tile[1]))
+    o_inst, o_tri, o_t, o_b = oracle.primary_ids(sc.desc, cam, w, h, tile, seeds)
+    r = make_renderer(sc, w, h, 3, tile, accel)
+    r.upload_seeds(seeds)
+    g_inst, g_tri, g_t, g_b = r.primary_ids(cam, 0)
+    r.close()
+    differ = (g_inst != o_inst) | (g_tri != o_tri)
+    if accel == hip.ACCEL_REFERENCE:
+        assert not differ.any()
+        assert (g_t.view(np.uint32) == o_t.view(np.uint32)).all()
+        assert (g_b.view(np.uint32) == o_b.view(np.uint32)).all()
+    else:
+        # same hit/miss decision everywhere; where the ids differ, both found a hit at the
+        # same distance (a shared edge or coplanar duplicate: whichever is tested last wins)
+        assert ((g_inst == hip.MISS) == (o_inst == oracle.MISS)).all()
+        assert differ.mean() <= 1e-3
+        assert (ulp_distance(g_t[differ], o_t[differ]) <= 4).all()
+        same = ~differ
+        assert (g_t[same].view(np.uint32) == o_t[same].view(np.uint32)).all()
+        assert (g_b[same].view(np.uint32) == o_b[same].view(np.uint32)).all()
+    return int(differ.sum())
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_primary_ids_cornell(cornell, accel):
+    check_ids(cornell, 400, 400, (100, 100), accel)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_primary_ids_hyperion(hyperion, accel):
+    check_ids(hyperion, 640, 360, (128, 72), accel)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_primary_ids_instanced_scene_beyond_reference_limits(instanced, accel):
+    # 1604 instances: rays cross far more than the shader's 15-entry candidate list
+    check_ids(instanced, 320, 180, (64, 36), accel)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light"])
+def test_golden_fixture(name, accel, cornell, hyperion):
+    sc = cornell if name == "cornell_box" else hyperion
+    z = np.load(os.path.join(GOLDEN, f"oracle_{name}.npz"))
+    w, h, tw, th, spp, md = (int(v) for v in z["params"])
+    seeds = host.seed_schedule(0, spp, (w // tw) * (h // th))
+    r = make_renderer(sc, w, h, md, (tw, th), accel)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(sc.camera(w, h), 0, spp)
+    got, passes = r.read_accum()
+    st = r.stats()
+    r.close()
+    assert passes == spp
+    assert_image_close(got, z["accum"], f"{name} accel {accel}")
+    assert abs(st["closest_rays"] - int(z["closest_rays"])) <= 8
+    assert abs(st["shadow_rays"] - int(z["shadow_rays"])) <= 8
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_image_parity_hyperion_depth7(hyperion, accel):
+    w, h, tile, spp, md = 320, 180, (64, 36), 8, 7
+    cam = hyperion.camera(w, h)
+    seeds = host.seed_schedule(0, spp, 25)
+    want, ost = oracle.render(hyperion.desc, cam, w, h, md, tile, seeds)
+    r = make_renderer(hyperion, w, h, md, tile, accel, flags=hip.FLAG_COUNT_NODES)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cam, 0, spp)
+    got, _ = r.read_accum()
+    st = r.stats()
+    r.close()
+    assert_image_close(got, want, f"hyperion accel {accel}")
+    assert st["samples"] == ost["samples"] == w * h * spp
+    assert abs(st["closest_rays"] - ost["closest_rays"]) <= 16
+    assert abs(st["closest_hits"] - ost["closest_hits"]) <= 16
+    assert abs(st["shadow_rays"] - ost["shadow_rays"]) <= 16
+    assert st["nodes_visited"] > 0 and st["tris_tested"] > 0
+    if accel == hip.ACCEL_REBUILT:
+        # the rebuilt tree is the point of that mode: far fewer node visits per ray
+        assert st["nodes_visited"] < 0.4 * ost["nodes_visited"]
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_image_parity_textures_and_environment_map(textured, accel):
+    info = textured.info
+    w, h, tile, md, spp = info.resolution_x, info.resolution_y, (40, 30), info.max_depth, 8
+    cam = textured.camera(w, h)
+    seeds = host.seed_schedule(0, spp, 16)
+    want, ost = oracle.render(textured.desc, cam, w, h, md, tile, seeds)
+    r = make_renderer(textured, w, h, md, tile, accel)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cam, 0, spp)
+    got, _ = r.read_accum()
+    st = r.stats()
+    r.close()
+    assert_image_close(got, want, f"textured accel {accel}")
+    assert abs(st["shadow_rays"] - ost["shadow_rays"]) <= 16
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_image_parity_instanced(instanced, accel):
+    w, h, tile, md, spp = 320, 180, (64, 36), 7, 2
+    cam = instanced.camera(w, h)
+    seeds = host.seed_schedule(0, spp, 25)
+    want, _ = oracle.render(instanced.desc, cam, w, h, md, tile, seeds)
+    r = make_renderer(instanced, w, h, md, tile, accel)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cam, 0, spp)
+    got, _ = r.read_accum()
+    r.close()
+    assert_image_close(got, want, f"instanced accel {accel}")
+
+
+def test_tile_cadence_equals_batched_render(cornell):
+    """One reference dispatch per (pass, tile) through rt_hip_render_tile gives the same bits
+    as the batched launch, and the pass counter advances when the last tile is done."""
+    w, h, tile, md, spp = 128, 96, (32, 32), 4, 3
+    cam = cornell.camera(w, h)
+    seeds = host.seed_schedule(0, spp, 12)
+    r = make_renderer(cornell, w, h, md, tile, hip.ACCEL_REBUILT)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cam, 0, spp)
+    batched, passes = r.read_accum()
+    assert passes == spp
+    r.clear()
+    for p in range(spp):
+        for ty in range(3):
+            for tx in range(4):
+                _, done = r.read_accum()
+                assert done == p
+                r.render_tile(cam, int(seeds[p, ty * 4 + tx]), tx, ty)
+    tiled, passes = r.read_accum()
+    r.close()
+    assert passes == spp
+    assert (tiled == batched).all()
+    want, _ = oracle.render(cornell.desc, cam, w, h, md, tile, seeds)
+    assert_image_close(tiled, want, "tile cadence")
+
+
+def test_preview_path(cornell):
+    """camera.dirty branch: (W/10) x (H/10) image, stored not accumulated, accumulation reset."""
+    w, h, tile, md = 640, 480, (160, 120), 3
+    pw, ph = w // 10, h // 10
+    r = make_renderer(cornell, w, h, md, tile, hip.ACCEL_REFERENCE)
+    r.upload_seeds(host.seed_schedule(0, 1, 16))
+    r.clear()
+    r.render(cornell.camera(w, h), 0, 1)
+    assert r.read_accum()[1] == 1
+    pcam = cornell.camera(pw, ph)
+    r.render_preview(pcam, 0xC0FFEE)
+    r.render_preview(pcam, 0xC0FFEE)  # second call overwrites, does not add
+    got = r.read_preview()
+    assert r.read_accum()[1] == 0
+    r.close()
+    want, _ = oracle.render(cornell.desc, pcam, pw, ph, md, (pw, ph),
+                            np.array([[0xC0FFEE]], dtype=np.uint32), preview=True)
+    assert got.shape == (ph, pw, 4)
+    assert_image_close(got, want, "preview")
+
+
+def test_error_behaviour(cornell):
+    with pytest.raises(RuntimeError, match="divisible"):
+        hip.HipRenderer(100, 100, 3, (30, 50))
+    r = hip.HipRenderer(64, 64, 3, (32, 32))
+    cam = cornell.camera(64, 64)
+    with pytest.raises(RuntimeError, match="no scene"):
+        r.render(cam, 0, 1)
+    r.upload_scene(cornell.desc)
+    with pytest.raises(RuntimeError, match="seeds"):
+        r.render(cam, 0, 1)
+    r.upload_seeds(host.seed_schedule(0, 2, 4))
+    with pytest.raises(RuntimeError, match="seeds"):
+        r.render(cam, 1, 2)  # pass 2 is not resident
+    with pytest.raises(RuntimeError, match="rectangle"):
+        r.render(cam, 0, 1, rect=(0, 0, 65, 64))
+    with pytest.raises(RuntimeError, match="tile"):
+        r.render_tile(cam, 1, 2, 0)
+    r.render(cam, 0, 0)  # zero passes: nothing to do, not an error
+    r.close()

@@ -1,0 +1,110 @@
+"""The oracle against its committed fixtures, its own invariants, and - loosely - against the
+one output of the reference itself that exists: the screenshot outputs/hyperion_rect_light.png
+(unknown sample count and seed, window-sized, tonemapped)."""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracing_amd import host
+
+from conftest import GOLDEN
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN, f"oracle_{name}.npz"))
+    w, h, tw, th, spp, md = (int(v) for v in z["params"])
+    return z, w, h, (tw, th), spp, md
+
+
+@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light"])
+def test_oracle_reproduces_golden_bit_for_bit(name, cornell, hyperion):
+    sc = cornell if name == "cornell_box" else hyperion
+    z, w, h, tile, spp, md = load_golden(name)
+    seeds = host.seed_schedule(0, spp, (w // tile[0]) * (h // tile[1]))
+    cam = sc.camera(w, h)
+    inst, tri, t, bary = oracle.primary_ids(sc.desc, cam, w, h, tile, seeds[:1])
+    assert (inst == z["instance"]).all() and (tri == z["triangle"]).all()
+    assert (t.view(np.uint32) == z["t"].view(np.uint32)).all()
+    assert (bary.view(np.uint32) == z["bary"].view(np.uint32)).all()
+    accum, stats = oracle.render(sc.desc, cam, w, h, md, tile, seeds)
+    assert stats["closest_rays"] == int(z["closest_rays"])
+    assert stats["shadow_rays"] == int(z["shadow_rays"])
+    # libm's sin/cos/pow may differ by an ulp between glibc versions; geometry may not
+    assert np.allclose(accum, z["accum"], rtol=1e-4, atol=1e-5)
+
+
+def test_oracle_pass_and_rect_splits_are_exact(cornell):
+    w, h, tile, md = 64, 48, (16, 16), 4
+    cam = cornell.camera(w, h)
+    seeds = host.seed_schedule(0, 4, 12)
+    whole, st = oracle.render(cornell.desc, cam, w, h, md, tile, seeds)
+    assert st["samples"] == w * h * 4
+    # passes [0,2) then [2,4) into the same accumulator == all four at once
+    part, _ = oracle.render(cornell.desc, cam, w, h, md, tile, seeds[:2])
+    part, _ = oracle.render(cornell.desc, cam, w, h, md, tile, seeds[2:], accum=part,
+                            first_pass=2)
+    assert (part == whole).all()
+    # tile by tile (the reference's dispatch cadence) == whole frame
+    tiled = np.zeros_like(whole)
+    for p in range(4):
+        for ty in range(3):
+            for tx in range(4):
+                oracle.render(cornell.desc, cam, w, h, md, tile, seeds[p:p + 1], accum=tiled,
+                              rect=(tx * 16, ty * 16, tx * 16 + 16, ty * 16 + 16))
+    assert (tiled == whole).all()
+    assert (whole[..., 3] == 1.0).all()
+    # thread count does not change anything
+    single, _ = oracle.render(cornell.desc, cam, w, h, md, tile, seeds, threads=1)
+    assert (single == whole).all()
+
+
+def test_oracle_preview_stores_instead_of_accumulating(cornell):
+    w, h, tile, md = 80, 80, (80, 80), 3
+    cam = cornell.camera(w, h)
+    seeds = host.seed_schedule(0, 1, 1)
+    first, _ = oracle.render(cornell.desc, cam, w, h, md, tile, seeds)
+    stale = np.full((h, w, 4), 7.0, dtype=np.float32)
+    stored, _ = oracle.render(cornell.desc, cam, w, h, md, tile, seeds, accum=stale, preview=True)
+    assert (stored == first).all()
+
+
+def test_max_depth_zero_is_direct_emission_only(cornell):
+    w, h, tile = 64, 64, (64, 64)
+    cam = cornell.camera(w, h)
+    seeds = host.seed_schedule(0, 1, 1)
+    img, st = oracle.render(cornell.desc, cam, w, h, 0, tile, seeds)
+    assert st["shadow_rays"] == 0 and st["closest_rays"] == w * h
+    lit = img[..., :3].sum(axis=2) > 0
+    assert 0 < lit.sum() < 0.05 * w * h           # only the ceiling light is visible
+    assert np.allclose(img[lit][:, :3], [17.0, 12.0, 4.0])
+
+
+def tonemap(accum, passes):
+    c = accum[..., :3] / passes
+    c = c / (c + 1.0)                             # to_ldr.glsl:1-3
+    return np.clip(c, 0, 1) ** (1 / 2.2)          # gamma_correct, :5-7
+
+
+def test_oracle_resembles_the_reference_screenshot(hyperion):
+    """Loose pin: same camera, same objects in the same places, similar brightness.
+    The screenshot is a 1274x712 window capture (the render is 1280x720) with an unknown
+    number of samples, so only coarse structure can be compared."""
+    from PIL import Image
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "ref_hyperion_thumb.png")).convert("RGB"),
+                     dtype=np.float32) / 255.0
+    w, h, tile, spp = 160, 90, (32, 18), 48
+    seeds = host.seed_schedule(0, spp, 25)
+    accum, _ = oracle.render(hyperion.desc, hyperion.camera(w, h), w, h, 5, tile, seeds)
+    mine = tonemap(accum, spp)
+
+    def coarse(img):  # 10x10 box average -> 9 x 16 cells
+        return img.reshape(9, 10, 16, 10, 3).mean(axis=(1, 3))
+
+    a, b = coarse(mine), coarse(ref)
+    corr = np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1]
+    assert corr > 0.95, corr
+    assert abs(a.mean() - b.mean()) < 0.05
+    # red floor: red dominates in both
+    assert a[..., 0].mean() > 2 * a[..., 1].mean() and b[..., 0].mean() > 2 * b[..., 1].mean()

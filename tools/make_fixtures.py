@@ -1,0 +1,79 @@
+"""Regenerates everything under tests/golden/ (run in the build container, needs the
+reference checkout at /root/reference for the asset files and its screenshot).
+
+  scenes/<name>.rtsnap        loader output for the reference's shipped scenes
+  oracle_<name>.npz           small fixed-seed oracle renders + primary-hit id maps
+  ref_hyperion_thumb.png      down-scaled copy of the reference's own screenshot
+                              (outputs/hyperion_rect_light.png), the only output of the
+                              reference itself that a render can be compared with
+  workload_constants.json     oracle counters on the reference BVH at the bench resolution:
+                              nodes and triangles per ray, rays per sample (roofline inputs)
+
+The oracle images are produced by oracle/oracle.c itself: they pin the oracle (and through it
+the HIP kernels) against regressions, they are NOT outputs of the reference.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import oracle  # noqa: E402
+from raytracing_amd import host  # noqa: E402
+
+REF = "/root/reference"
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+# name -> (width, height, tile, spp, max_depth) of the small golden render
+SMALL = {
+    "cornell_box": (96, 96, (24, 24), 4, 3),
+    "hyperion_rect_light": (160, 90, (32, 18), 4, 5),
+}
+
+
+def main():
+    os.makedirs(os.path.join(GOLDEN, "scenes"), exist_ok=True)
+    constants = {}
+    for name, (w, h, tile, spp, md) in SMALL.items():
+        sc = host.HostScene.from_json(os.path.join(REF, "assets", name + ".json"))
+        sc.save_snapshot(os.path.join(GOLDEN, "scenes", name + ".rtsnap"))
+        cam = sc.camera(w, h)
+        tiles = (w // tile[0]) * (h // tile[1])
+        seeds = host.seed_schedule(0, spp, tiles)
+        accum, stats = oracle.render(sc.desc, cam, w, h, md, tile, seeds)
+        inst, tri, t, bary = oracle.primary_ids(sc.desc, cam, w, h, tile, seeds[:1])
+        np.savez_compressed(os.path.join(GOLDEN, f"oracle_{name}.npz"), accum=accum,
+                            instance=inst, triangle=tri, t=t, bary=bary,
+                            params=np.array([w, h, tile[0], tile[1], spp, md], dtype=np.uint32),
+                            closest_rays=np.uint64(stats["closest_rays"]),
+                            shadow_rays=np.uint64(stats["shadow_rays"]))
+        print(name, "golden", accum.shape, stats)
+
+        # Roofline inputs at the bench configuration: 1280x720, max_depth 7, 2 passes.
+        bw, bh, btile, bmd = 1280, 720, (128, 72), 7
+        bseeds = host.seed_schedule(0, 2, (bw // btile[0]) * (bh // btile[1]))
+        _, bstats = oracle.render(sc.desc, sc.camera(bw, bh), bw, bh, bmd, btile, bseeds)
+        rays = bstats["closest_rays"] + bstats["shadow_rays"]
+        constants[name] = {
+            "config": {"width": bw, "height": bh, "max_depth": bmd, "passes": 2},
+            "closest_rays_per_sample": bstats["closest_rays"] / bstats["samples"],
+            "shadow_rays_per_sample": bstats["shadow_rays"] / bstats["samples"],
+            "nodes_per_ray": bstats["nodes_visited"] / rays,
+            "tris_per_ray": bstats["tris_tested"] / rays,
+            "max_stack": bstats["max_stack"],
+            "tlas_depth": sc.info.tlas_depth, "blas_depth": sc.info.blas_depth,
+        }
+        print(name, "constants", constants[name])
+    with open(os.path.join(GOLDEN, "workload_constants.json"), "w") as f:
+        json.dump(constants, f, indent=2, sort_keys=True)
+
+    from PIL import Image
+    shot = Image.open(os.path.join(REF, "outputs", "hyperion_rect_light.png")).convert("RGB")
+    shot.resize((160, 90), Image.BOX).save(os.path.join(GOLDEN, "ref_hyperion_thumb.png"))
+
+
+if __name__ == "__main__":
+    main()
