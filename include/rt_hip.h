@@ -113,6 +113,11 @@ int rt_hip_read_preview(rt_hip_renderer* r, float* rgba, void* stream);
 /* Device address of the renderer's own accumulator (for a collective). */
 int rt_hip_accum_ptr(rt_hip_renderer* r, void** accum_dev);
 
+/* Complete passes accumulated so far in the renderer's own accumulator (the
+ * reference's accumulation_counter, megakernel_raytracer.cpp:109, :667-669).
+ * Does not synchronise. */
+int rt_hip_passes(rt_hip_renderer* r, uint32_t* passes);
+
 /* Tell the renderer how many complete passes its accumulator holds (used
  * after an external reduce into it). */
 int rt_hip_set_passes(rt_hip_renderer* r, uint32_t passes);

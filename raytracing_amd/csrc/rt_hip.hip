@@ -814,6 +814,15 @@ int rt_hip_accum_ptr(rt_hip_renderer* r, void** accum_dev) {
     });
 }
 
+int rt_hip_passes(rt_hip_renderer* r, uint32_t* passes) {
+    return guarded([&] {
+        if (!r || !passes) {
+            throw std::runtime_error("passes: null argument");
+        }
+        *passes = r->passes_done;
+    });
+}
+
 int rt_hip_set_passes(rt_hip_renderer* r, uint32_t passes) {
     return guarded([&] {
         if (!r) {

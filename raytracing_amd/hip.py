@@ -20,7 +20,8 @@ MISS = 0xFFFFFFFF
 EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
     "rt_hip_render", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
-    "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_set_passes",
+    "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
+    "rt_hip_set_passes",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
@@ -65,6 +66,7 @@ def lib():
         l.rt_hip_read_accum.argtypes = [C.c_void_p, fp, u32p, C.c_void_p]
         l.rt_hip_read_preview.argtypes = [C.c_void_p, fp, C.c_void_p]
         l.rt_hip_accum_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        l.rt_hip_passes.argtypes = [C.c_void_p, u32p]
         l.rt_hip_set_passes.argtypes = [C.c_void_p, C.c_uint32]
         l.rt_hip_stats.argtypes = [C.c_void_p, C.POINTER(T.Stats), C.c_int]
         l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
@@ -138,6 +140,11 @@ class HipRenderer:
         p = C.c_void_p()
         _check(lib().rt_hip_accum_ptr(self._h, C.byref(p)))
         return p.value
+
+    def passes(self):
+        n = C.c_uint32()
+        _check(lib().rt_hip_passes(self._h, C.byref(n)))
+        return n.value
 
     def set_passes(self, passes):
         _check(lib().rt_hip_set_passes(self._h, passes))

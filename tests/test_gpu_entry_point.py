@@ -1,0 +1,89 @@
+"""The headless `Raytracing <scene>` entry point: the reference's call sequence on the renderer
+table, driven through the HIP back end, must produce the same accumulation as driving the C
+ABI directly with the same seed stream."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+import torch  # noqa: F401
+
+import oracle
+from raytracing_amd import hip, host, scenes
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+BINARY = os.path.join(ROOT, "raytracing_amd", "bin", "Raytracing")
+
+
+def read_raw(path):
+    with open(path, "rb") as f:
+        assert f.read(8) == b"RTACCUM1"
+        w, h, passes = struct.unpack("<III", f.read(12))
+        data = np.frombuffer(f.read(), dtype=np.float32).reshape(h, w, 4)
+    return data, passes
+
+
+def run(args, cwd):
+    out = subprocess.run([BINARY] + args, cwd=cwd, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    return out.stdout
+
+
+def test_binary_exists():
+    assert os.path.exists(BINARY), "run __graft_entry__.build() first"
+
+
+@pytest.mark.parametrize("extra", [[], ["--batch", "3"], ["--preview-first"]])
+def test_entry_point_matches_direct_abi_calls(tmp_path, cornell, extra):
+    # cornell_box.json as shipped: 800x800, max_depth 3, 200x200 tiles -> 16 dispatches a pass
+    spp = 3
+    raw = str(tmp_path / "accum.bin")
+    png = str(tmp_path / "out.png")
+    stdout = run([scenes.snapshot_path("cornell_box"), "--spp", str(spp), "--raw", raw,
+                  "--out", png] + extra, str(tmp_path))
+    got, passes = read_raw(raw)
+    assert passes == spp and got.shape == (800, 800, 4)
+    assert "3 passes" in stdout
+    info = cornell.info
+    tile = (info.tile_width, info.tile_height)
+    # --preview-first consumes one word of the seed stream for the preview dispatch
+    shift = 1 if "--preview-first" in extra else 0
+    words = host.seed_schedule(0, 1, spp * 16 + shift)[0, shift:]
+    seeds = words.reshape(spp, 16)
+    r = hip.HipRenderer(800, 800, info.max_depth, tile)
+    r.upload_scene(cornell.desc)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cornell.camera(800, 800), 0, spp)
+    want, _ = r.read_accum()
+    r.close()
+    assert (got == want).all()
+    from PIL import Image
+    img = np.asarray(Image.open(png))
+    assert img.shape == (800, 800, 3) and img.mean() > 20
+
+
+def test_entry_point_reference_order_small_against_oracle(tmp_path, cornell):
+    spp = 2
+    raw = str(tmp_path / "accum.bin")
+    run([scenes.snapshot_path("cornell_box"), "--spp", str(spp), "--raw", raw,
+         "--reference-order", "--out", str(tmp_path / "o.png")], str(tmp_path))
+    got, passes = read_raw(raw)
+    assert passes == spp
+    info = cornell.info
+    seeds = host.seed_schedule(0, spp, 16)
+    want, _ = oracle.render(cornell.desc, cornell.camera(800, 800), 800, 800, info.max_depth,
+                            (200, 200), seeds)
+    err = np.abs(got[..., :3] - want[..., :3])
+    assert (err > 1e-3 * np.abs(want[..., :3]) + 1e-4).mean() < 2e-3
+
+
+def test_entry_point_errors(tmp_path):
+    out = subprocess.run([BINARY, str(tmp_path / "missing.json")], capture_output=True, text=True)
+    assert out.returncode != 0 and "cannot open" in out.stderr
+    out = subprocess.run([BINARY], capture_output=True, text=True)
+    assert out.returncode == 2
