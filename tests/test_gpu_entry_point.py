@@ -61,7 +61,9 @@ def test_entry_point_matches_direct_abi_calls(tmp_path, cornell, extra):
     r.render(cornell.camera(800, 800), 0, spp)
     want, _ = r.read_accum()
     r.close()
-    assert (got == want).all()
+    # the shader can produce NaN radiance (a light sample seen exactly edge-on has pdf = inf
+    # and power_heuristic(inf, x) = inf/inf); both paths must agree on those pixels too
+    assert np.array_equal(got, want, equal_nan=True)
     from PIL import Image
     img = np.asarray(Image.open(png))
     assert img.shape == (800, 800, 3) and img.mean() > 20
@@ -78,8 +80,9 @@ def test_entry_point_reference_order_small_against_oracle(tmp_path, cornell):
     seeds = host.seed_schedule(0, spp, 16)
     want, _ = oracle.render(cornell.desc, cornell.camera(800, 800), 800, 800, info.max_depth,
                             (200, 200), seeds)
-    err = np.abs(got[..., :3] - want[..., :3])
-    assert (err > 1e-3 * np.abs(want[..., :3]) + 1e-4).mean() < 2e-3
+    assert (np.isnan(got) == np.isnan(want)).mean() > 1 - 1e-5
+    err = np.nan_to_num(np.abs(got[..., :3] - want[..., :3]))
+    assert (err > 1e-3 * np.abs(np.nan_to_num(want[..., :3])) + 1e-4).mean() < 2e-3
 
 
 def test_entry_point_errors(tmp_path):
