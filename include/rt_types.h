@@ -165,6 +165,8 @@ typedef struct rt_stats {
     uint64_t nodes_visited; /* BVH nodes fetched (TLAS + BLAS) */
     uint64_t tris_tested;   /* ray/triangle tests */
     uint64_t max_stack;     /* deepest traversal stack seen */
+    uint64_t shadow_skipped;/* occlusion rays the shader traces although the light sample is
+                               then discarded (BSDF pdf <= 0); not traced, not in shadow_rays */
     double   seconds;       /* device time of the counted launches */
 } rt_stats;
 

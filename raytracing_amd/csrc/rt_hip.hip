@@ -22,29 +22,47 @@ using namespace rtd;
 
 namespace {
 
-constexpr uint32_t kCounterWords = 7;  // samples, closest, shadow, hits, nodes, tris, max_stack
+// samples, closest, shadow, hits, nodes, tris, max_stack, shadow_skipped
+constexpr uint32_t kCounterWords = 8;
 constexpr uint32_t kPreviewRatio = 10; // src/renderer/megakernel_raytracer.cpp:54
 
-// Pixel owned by this lane: waves cover 8x8 pixel blocks of the rectangle, and
-// consecutive block ids that share an XCD (ids equal mod 8) are given
-// neighbouring screen blocks so each XCD's L2 sees a compact part of the scene.
+// Pixel owned by this lane: a wave covers one 8x8 pixel block of the rectangle.
+// Workgroups are dealt round-robin over the 8 XCDs (ids equal mod 8 share an
+// XCD and its L2).  Block rows are interleaved over the XCDs: ids 8j..8j+7 are
+// the same block column in 8 consecutive block rows, so every XCD walks the
+// whole picture in 8-pixel-high strips.  Each L2 still sees spatially coherent
+// rays, and an expensive region of the image is shared by all XCDs instead of
+// leaving seven of them idle (contiguous per-XCD bands measured ~1.4 resident
+// waves per SIMD on average because of that tail).
 __device__ __forceinline__ bool lane_pixel(render_params const& p, uint32_t& x, uint32_t& y) {
     uint32_t const blocks_x = (p.x1 - p.x0 + 7u) / 8u;
-    uint32_t const total = gridDim.x;
-    uint32_t const xcd = blockIdx.x % 8u;
-    uint32_t const q = total / 8u, r = total % 8u;
-    uint32_t const start = xcd < r ? xcd * (q + 1u) : r * (q + 1u) + (xcd - r) * q;
-    uint32_t const block = start + blockIdx.x / 8u;
-    uint32_t const bx = block % blocks_x;
-    uint32_t const by = block / blocks_x;
+    uint32_t const blocks_y = (p.y1 - p.y0 + 7u) / 8u;
+    uint32_t const full_rows = blocks_y & ~7u;        // rows that interleave evenly
+    uint32_t const full_blocks = full_rows * blocks_x;
+    uint32_t const i = blockIdx.x;
+    uint32_t bx, by;
+    if (i < full_blocks) {
+        uint32_t const j = i / 8u;
+        bx = j % blocks_x;
+        by = (j / blocks_x) * 8u + (i % 8u);
+    } else {
+        uint32_t const t = i - full_blocks;
+        bx = t % blocks_x;
+        by = full_rows + t / blocks_x;
+    }
     uint32_t const lane = threadIdx.x;
     x = p.x0 + bx * 8u + (lane & 7u);
     y = p.y0 + by * 8u + (lane >> 3);
     return x < p.x1 && y < p.y1;
 }
 
+// Second launch-bound argument = minimum waves per SIMD the register allocation must allow.
+#ifndef RT_WAVES_PER_SIMD
+#define RT_WAVES_PER_SIMD 4
+#endif
+
 template <int ACCEL, bool COUNT>
-__global__ void __launch_bounds__(64) path_trace_kernel(render_params const p) {
+__global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(render_params const p) {
     __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
     fast_stack stk;
     stk.lds = lds_stack + threadIdx.x;
@@ -62,80 +80,100 @@ __global__ void __launch_bounds__(64) path_trace_kernel(render_params const p) {
     }
 
     trace_counters cnt;
-    uint32_t closest_rays = 0, shadow_rays = 0, closest_hits = 0;
+    uint32_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, shadow_skipped = 0;
 
+    // Each trip of the loop traces one ray pair - the previous bounce's occlusion ray, then
+    // this bounce's closest-hit ray - and shades the hit.  All shading of a bounce (light
+    // proposal, both BSDF evaluations, BSDF sampling) happens BEFORE its occlusion ray is
+    // traced: the next-event contribution is kept as three floats (`nee`) and added when the
+    // ray turns out unoccluded.  Nothing between the shader's occlusion test (:488) and the
+    // next bounce draws random numbers or adds to the radiance, so values and order of every
+    // addition are those of the shader; only the surface state no longer has to stay alive
+    // across a traversal.
     uint32_t pass = 0;
     uint32_t seed;
-    f3 origin, direction;
+    ray_pair rp;
+    rp.has_shadow = false;
+    rp.has_closest = true;
+    f3 nee = splat3(0.0f);
     f3 radiance = splat3(0.0f);
     f3 throughput = splat3(1.0f);
     float last_bsdf_pdf = 0.0f;
     uint32_t depth = 0;
-    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, origin, direction);
+    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, rp.origin, rp.direction);
 
     for (;;) {
-        bool path_done = false;
-        hit_result hr;
-        ++closest_rays;
-        bool const hit_any = trace_closest<ACCEL, COUNT>(sc, stk, origin, direction, hr, cnt);
-        if (!hit_any) {
-            // megakernel_raytracer.comp:518-527
-            f4 const ip = eval_sky_light(sc, direction);
-            if (ip.w > 0.0f) {
-                float const mis = depth > 0u ? power_heuristic(last_bsdf_pdf, ip.w) : 1.0f;
-                radiance = radiance + (mk3(ip.x, ip.y, ip.z) * mis) * throughput;
-            }
-            path_done = true;
-        } else {
-            ++closest_hits;
-            hit_state st;
-            fill_hit_state(sc, hr, origin, direction, st);
-            surface si;
-            make_surface(sc, st, si);
-            radiance = radiance + si.emission * throughput;
-            if (st.light >= 0 || depth == p.max_depth) {
-                path_done = true;
-            } else {
-                lobe_mix const lm = make_lobe_mix(st, si, direction);
-                // state.glsl:14-16 - undoes the ray-facing flip, so the offset follows the
-                // mesh's own normal direction even for back-face hits
-                f3 const front_face_normal = st.front_face ? st.normal : -st.normal;
-                f3 const shadow_origin = st.position + front_face_normal * kEpsilon;
-                light_sample ls;
-                bool have_light = propose_light(sc, seed, direction, shadow_origin, ls);
-                if (have_light) {
-                    ++shadow_rays;
-                    have_light = !trace_any<ACCEL, COUNT>(
-                        sc, stk, shadow_origin, ls.wi, ls.shadow_t_max, cnt);
+        pair_result pr;
+        closest_rays += rp.has_closest ? 1u : 0u;
+        shadow_rays += rp.has_shadow ? 1u : 0u;
+        trace_pair<ACCEL, COUNT>(sc, stk, rp, pr, cnt);
+        if (rp.has_shadow && !pr.occluded) {
+            radiance = radiance + nee;  // :547-549
+        }
+        rp.has_shadow = false;
+        if (rp.has_closest) {
+            rp.has_closest = false;  // set again below when the path goes on
+            if (!pr.hit) {
+                // :518-527
+                f4 const ip = eval_sky_light(sc, rp.direction);
+                if (ip.w > 0.0f) {
+                    float const mis = depth > 0u ? power_heuristic(last_bsdf_pdf, ip.w) : 1.0f;
+                    radiance = radiance + (mk3(ip.x, ip.y, ip.z) * mis) * throughput;
                 }
-                f3 const next_direction = sample_disney(seed, st, si, lm);
-                // One eval_disney body serves both uses (:541-550 and :554-560).
+            } else {
+                ++closest_hits;
+                hit_state st;
+                fill_hit_state(sc, pr.best, rp.origin, rp.direction, st);
+                surface si;
+                make_surface(sc, st, si);
+                radiance = radiance + si.emission * throughput;
+                if (st.light < 0 && depth != p.max_depth) {
+                    lobe_mix const lm = make_lobe_mix(st, si, rp.direction);
+                    // state.glsl:14-16 - undoes the ray-facing flip, so the offset follows the
+                    // mesh's own normal direction even for back-face hits
+                    f3 const front_face_normal = st.front_face ? st.normal : -st.normal;
+                    f3 const shadow_origin = st.position + front_face_normal * kEpsilon;
+                    light_sample ls;
+                    bool const have_light =
+                        propose_light(sc, seed, rp.direction, shadow_origin, ls);
+                    f3 const next_direction = sample_disney(seed, st, si, lm);
+                    // One eval_disney body serves both uses (:541-550 and :554-560).
 #pragma nounroll
-                for (int k = have_light ? 0 : 1; k < 2; ++k) {
-                    f3 const l = k == 0 ? ls.wi : next_direction;
-                    f4 const bsdf = eval_disney(st, si, lm, l);
-                    if (k == 0) {
-                        if (bsdf.w > 0.0f) {
-                            bool const is_delta = ls.type == RT_LIGHT_DISTANT;
-                            float const mis = is_delta ? 1.0f : power_heuristic(ls.pdf, bsdf.w);
-                            f3 const f = mk3(bsdf.x, bsdf.y, bsdf.z);
-                            radiance = radiance + (((f * mis) * ls.intensity) / ls.pdf) * throughput;
-                        }
-                    } else {
-                        last_bsdf_pdf = bsdf.w;
-                        if (bsdf.w > 0.0f) {
-                            throughput = throughput * (mk3(bsdf.x, bsdf.y, bsdf.z) / bsdf.w);
+                    for (int k = have_light ? 0 : 1; k < 2; ++k) {
+                        f3 const l = k == 0 ? ls.wi : next_direction;
+                        f4 const bsdf = eval_disney(st, si, lm, l);
+                        if (k == 0) {
+                            if (bsdf.w > 0.0f) {
+                                bool const is_delta = ls.type == RT_LIGHT_DISTANT;
+                                float const mis =
+                                    is_delta ? 1.0f : power_heuristic(ls.pdf, bsdf.w);
+                                f3 const f = mk3(bsdf.x, bsdf.y, bsdf.z);
+                                nee = (((f * mis) * ls.intensity) / ls.pdf) * throughput;
+                                rp.has_shadow = true;
+                                rp.shadow_origin = shadow_origin;
+                                rp.shadow_direction = ls.wi;
+                                rp.shadow_t_max = ls.shadow_t_max;
+                            } else {
+                                // the shader traces this occlusion ray and then discards the
+                                // sample (pdf <= 0): its outcome cannot reach the image
+                                ++shadow_skipped;
+                            }
                         } else {
-                            path_done = true;
+                            last_bsdf_pdf = bsdf.w;
+                            if (bsdf.w > 0.0f) {
+                                throughput = throughput * (mk3(bsdf.x, bsdf.y, bsdf.z) / bsdf.w);
+                                rp.has_closest = true;
+                            }
                         }
                     }
+                    rp.direction = next_direction;
+                    rp.origin = st.position + next_direction * kEpsilon;
+                    ++depth;
                 }
-                direction = next_direction;
-                origin = st.position + next_direction * kEpsilon;
-                ++depth;
             }
         }
-        if (path_done) {
+        if (!rp.has_closest && !rp.has_shadow) {
+            // the path is over and its last occlusion ray is resolved
             acc = p.preview ? radiance : acc + radiance;
             ++pass;
             if (pass == p.pass_count) {
@@ -144,7 +182,8 @@ __global__ void __launch_bounds__(64) path_trace_kernel(render_params const p) {
             radiance = splat3(0.0f);
             throughput = splat3(1.0f);
             depth = 0;
-            primary_ray(p, x, y, pass_seed(p, pass, x, y), seed, origin, direction);
+            rp.has_closest = true;
+            primary_ray(p, x, y, pass_seed(p, pass, x, y), seed, rp.origin, rp.direction);
         }
     }
     *reinterpret_cast<float4*>(px) = make_float4(acc.x, acc.y, acc.z, 1.0f);
@@ -155,6 +194,7 @@ __global__ void __launch_bounds__(64) path_trace_kernel(render_params const p) {
         atomicAdd(&p.counters[1], (unsigned long long) closest_rays);
         atomicAdd(&p.counters[2], (unsigned long long) shadow_rays);
         atomicAdd(&p.counters[3], (unsigned long long) closest_hits);
+        atomicAdd(&p.counters[7], (unsigned long long) shadow_skipped);
         if (COUNT) {
             atomicAdd(&p.counters[4], (unsigned long long) cnt.nodes);
             atomicAdd(&p.counters[5], (unsigned long long) cnt.tris);
@@ -173,15 +213,15 @@ __global__ void __launch_bounds__(64) primary_ids_kernel(render_params const p) 
         return;
     }
     uint32_t seed;
-    f3 origin, direction;
-    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, origin, direction);
-    hit_result hr;
-    hr.instance = RT_HIP_MISS;
-    hr.triangle = RT_HIP_MISS;
-    hr.b0 = hr.b1 = hr.b2 = 0.0f;
-    hr.t = kInfinity;
+    ray_pair rp;
+    rp.has_shadow = false;
+    rp.has_closest = true;
+    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, rp.origin, rp.direction);
+    pair_result pr;
     trace_counters cnt;
-    bool const hit = trace_closest<ACCEL, false>(p.sc, stk, origin, direction, hr, cnt);
+    trace_pair<ACCEL, false>(p.sc, stk, rp, pr, cnt);
+    bool const hit = pr.hit;
+    hit_result const& hr = pr.best;
     size_t const i = (size_t) y * p.frame_width + x;
     if (p.out_instance) {
         p.out_instance[i] = hit ? hr.instance : RT_HIP_MISS;
@@ -850,6 +890,7 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
             out->nodes_visited = words[4];
             out->tris_tested = words[5];
             out->max_stack = words[6];
+            out->shadow_skipped = words[7];
             out->seconds = r->seconds_total;
         }
         if (reset) {

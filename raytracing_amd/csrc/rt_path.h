@@ -33,24 +33,25 @@ struct render_params {
     float* out_bary;
 };
 
+// Traces a bounce's occlusion ray (optional) and the following closest-hit ray
+// (optional).  The reference-order mode runs its two walks back to back; the
+// rebuilt mode runs both inside one loop (rt_traverse_fast.h).
 template <int ACCEL, bool COUNT>
-RT_DEV bool trace_closest(scene_dev const& sc, fast_stack const& stk, f3 o, f3 d,
-    hit_result& hr, trace_counters& c) {
+RT_DEV void trace_pair(scene_dev const& sc, fast_stack const& stk, ray_pair const& rp,
+    pair_result& out, trace_counters& c) {
     if (ACCEL == RT_HIP_ACCEL_REFERENCE) {
-        return trace_ref<false, COUNT>(sc, o, d, kInfinity, hr, c);
+        out.occluded = false;
+        out.hit = false;
+        if (rp.has_shadow) {
+            hit_result unused;
+            out.occluded = trace_ref<true, COUNT>(
+                sc, rp.shadow_origin, rp.shadow_direction, rp.shadow_t_max, unused, c);
+        }
+        if (rp.has_closest) {
+            out.hit = trace_ref<false, COUNT>(sc, rp.origin, rp.direction, kInfinity, out.best, c);
+        }
     } else {
-        return trace_fast<false, COUNT>(sc, stk, o, d, kInfinity, hr, c);
-    }
-}
-
-template <int ACCEL, bool COUNT>
-RT_DEV bool trace_any(scene_dev const& sc, fast_stack const& stk, f3 o, f3 d, float t_max,
-    trace_counters& c) {
-    hit_result unused;
-    if (ACCEL == RT_HIP_ACCEL_REFERENCE) {
-        return trace_ref<true, COUNT>(sc, o, d, t_max, unused, c);
-    } else {
-        return trace_fast<true, COUNT>(sc, stk, o, d, t_max, unused, c);
+        trace_pair_fast<COUNT>(sc, stk, rp, out, c);
     }
 }
 

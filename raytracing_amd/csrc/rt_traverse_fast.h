@@ -10,6 +10,10 @@
 //   * TLAS and BLAS walked in ONE loop with one stack: entering an instance
 //     pushes a marker and switches the ray to object space, popping the
 //     marker switches back, so the wave never re-converges per instance;
+//   * per-ray set-up (reciprocals, shear constants) runs for the whole wave
+//     before each walk, never inside the divergent loop: with trees this
+//     shallow a ray visits only a handful of nodes, so serialised set-up
+//     would cost more than the walk itself;
 //   * the traversal stack lives in LDS (stack[entry][lane]: conflict-free for
 //     a wave), with a private overflow area that is essentially never used;
 //   * nearer child first by entry distance; the farther child is pushed and
@@ -62,9 +66,28 @@ RT_DEV void slab_box(slab_ray const& r, float lox, float loy, float loz, float h
     t_exit = fminf(fminf(fx, fy), fminf(fz, t_max)) * 1.0000002f;
 }
 
+// One bounce's ray pair.  The occlusion ray (if any) is traced first over
+// (0, shadow_t_max]; then the closest-hit ray (if any) over (0, 1e14].
+struct ray_pair {
+    bool has_shadow;
+    bool has_closest;
+    f3 shadow_origin, shadow_direction;
+    float shadow_t_max;
+    f3 origin, direction;
+};
+
+struct pair_result {
+    bool occluded;  // the occlusion ray hit something
+    bool hit;       // the closest-hit ray hit something (best is valid)
+    hit_result best;
+};
+
+// ANY = false: closest hit (best is filled, returns whether anything was hit).
+// ANY = true : occlusion query over (0, t_limit]; returns on the first hit.
+// Lanes with active == false skip the walk (their ray does not exist).
 template <bool ANY, bool COUNT>
-RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, f3 origin, f3 direction,
-    float t_limit, hit_result& best, trace_counters& cnt) {
+RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, f3 origin,
+    f3 direction, float t_limit, hit_result& best, trace_counters& cnt) {
     uint32_t spill[kFastSpillEntries];
     uint32_t sp = 0;
     auto push = [&](int32_t v) {
@@ -89,12 +112,16 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, f3 origin, f3
 
     float t_max = t_limit;
     bool found = false;
+    // Ray set-up runs for the whole wave at once, outside the divergent loop.
     slab_ray const world_slab = make_slab_ray(origin, direction);
     slab_ray slab = world_slab;
     tri_ray tr = make_tri_ray(origin, direction);
     uint32_t current_instance = 0;
     int32_t cur = sc.wide_tlas_root;
     bool in_blas = false;
+    if (!active) {
+        return false;
+    }
 
     for (;;) {
         if (cur >= 0) {
@@ -123,8 +150,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, f3 origin, f3
         } else if (!in_blas) {
             // TLAS leaf: exactly one instance.  Enter its BLAS.
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-            const float4* rp = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
-            float4 const r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+            float4 const r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
             // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
             f3 o, d;
             o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
@@ -181,6 +208,16 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, f3 origin, f3
             slab = world_slab;
         }
     }
+}
+
+template <bool COUNT>
+RT_DEV void trace_pair_fast(scene_dev const& sc, fast_stack const& stk, ray_pair const& rp,
+    pair_result& out, trace_counters& cnt) {
+    hit_result unused;
+    out.occluded = trace_fast<true, COUNT>(sc, stk, rp.has_shadow, rp.shadow_origin,
+        rp.shadow_direction, rp.shadow_t_max, unused, cnt);
+    out.hit = trace_fast<false, COUNT>(
+        sc, stk, rp.has_closest, rp.origin, rp.direction, kInfinity, out.best, cnt);
 }
 
 }  // namespace rtd

@@ -84,7 +84,7 @@ class Stats(C.Structure):
                 ("shadow_rays", C.c_uint64), ("closest_hits", C.c_uint64),
                 ("nodes_visited", C.c_uint64),
                 ("tris_tested", C.c_uint64), ("max_stack", C.c_uint64),
-                ("seconds", C.c_double)]
+                ("shadow_skipped", C.c_uint64), ("seconds", C.c_double)]
 
     def as_dict(self):
         return {name: getattr(self, name) for name, _ in self._fields_}
@@ -100,7 +100,7 @@ class HostInfo(C.Structure):
 
 _EXPECTED_SIZES = {BvhNode: 40, Mesh: 12, Instance: 20, Vertex: 32, Triangle: 96, Mat4: 64,
                    Material: 96, Medium: 32, Light: 48, Texture: 24, Camera: 48,
-                   SceneDesc: 11 * 8 + 12 * 4, Stats: 64}
+                   SceneDesc: 11 * 8 + 12 * 4, Stats: 72}
 for _cls, _size in _EXPECTED_SIZES.items():
     assert C.sizeof(_cls) == _size, (_cls.__name__, C.sizeof(_cls), _size)
 

@@ -9,7 +9,9 @@ import numpy as np
 
 from . import ctypes_defs as T
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "librt_hip.so")
+# RT_HIP_LIB selects another build of the same library (kernel A/B experiments).
+_LIB_PATH = os.environ.get("RT_HIP_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "lib", "librt_hip.so")
 _lib = None
 
 ACCEL_REFERENCE = 0

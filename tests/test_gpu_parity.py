@@ -113,7 +113,8 @@ def test_golden_fixture(name, accel, cornell, hyperion):
     assert passes == spp
     assert_image_close(got, z["accum"], f"{name} accel {accel}")
     assert abs(st["closest_rays"] - int(z["closest_rays"])) <= 8
-    assert abs(st["shadow_rays"] - int(z["shadow_rays"])) <= 8
+    # occlusion rays of light samples that the BSDF then rejects are not traced by the kernel
+    assert abs(st["shadow_rays"] + st["shadow_skipped"] - int(z["shadow_rays"])) <= 8
 
 
 @pytest.mark.parametrize("accel", ACCELS)
@@ -133,7 +134,7 @@ def test_image_parity_hyperion_depth7(hyperion, accel):
     assert st["samples"] == ost["samples"] == w * h * spp
     assert abs(st["closest_rays"] - ost["closest_rays"]) <= 16
     assert abs(st["closest_hits"] - ost["closest_hits"]) <= 16
-    assert abs(st["shadow_rays"] - ost["shadow_rays"]) <= 16
+    assert abs(st["shadow_rays"] + st["shadow_skipped"] - ost["shadow_rays"]) <= 16
     assert st["nodes_visited"] > 0 and st["tris_tested"] > 0
     if accel == hip.ACCEL_REBUILT:
         # the rebuilt tree is the point of that mode: far fewer node visits per ray
@@ -155,7 +156,7 @@ def test_image_parity_textures_and_environment_map(textured, accel):
     st = r.stats()
     r.close()
     assert_image_close(got, want, f"textured accel {accel}")
-    assert abs(st["shadow_rays"] - ost["shadow_rays"]) <= 16
+    assert abs(st["shadow_rays"] + st["shadow_skipped"] - ost["shadow_rays"]) <= 16
 
 
 @pytest.mark.parametrize("accel", ACCELS)

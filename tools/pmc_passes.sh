@@ -1,0 +1,28 @@
+#!/bin/bash
+# Collects rocprofv3 PMC counters for the bench kernel, one pass per run (the hardware cannot
+# split counters over passes by itself).  usage: tools/pmc_passes.sh <out-prefix> [bench args]
+set -u
+OUT=$1; shift
+ROOT=${GRAFT_REPO_ROOT:-$PWD}
+cd /tmp && export TMPDIR=/tmp
+i=0
+for CTRS in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_VMEM_RD" \
+  "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_THREAD_CYCLES_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VALU_TRANS_F32" \
+  "TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" \
+  "FETCH_SIZE" \
+  "WRITE_SIZE" ; do
+  i=$((i+1))
+  timeout -s KILL 120 rocprofv3 --pmc $CTRS --output-format csv -d $ROOT/gpurun_out/${OUT}_p$i -o p -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${OUT}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $ROOT/gpurun_out/${OUT}_p$i.log; exit 1; }
+done
+python3 - <<PY
+import csv, glob, collections
+for d in sorted(glob.glob("$ROOT/gpurun_out/${OUT}_p*/")):
+    for f in glob.glob(d + "*counter_collection.csv"):
+        acc = collections.defaultdict(list)
+        for row in csv.DictReader(open(f)):
+            if "path_trace" in row["Kernel_Name"]:
+                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
+        for k, v in acc.items():
+            print(k, "n=%d" % len(v), "last=%.6g" % v[-1], "mean=%.6g" % (sum(v) / len(v)))
+PY
