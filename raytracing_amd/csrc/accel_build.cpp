@@ -51,7 +51,7 @@ struct build_prim {
 };
 
 constexpr int kBins = 16;
-constexpr uint32_t kDepthLimit = 40;   // beyond this, split by object median
+constexpr uint32_t kStackEntries = 32;  // = kFastLdsEntries of the traversal kernel
 constexpr float kTraversalCost = 1.2f;
 constexpr float kIntersectCost = 1.0f;
 
@@ -62,14 +62,29 @@ int32_t encode_leaf(uint32_t first, uint32_t count) {
 class tree_builder {
 public:
     // emit_leaf(prims, count) appends the leaf's payload and returns its first index.
+    // depth_limit: no inner node is created at this depth or beyond, i.e. a walk never has
+    // more than depth_limit pending siblings.  A subtree whose remaining levels would not
+    // suffice for SAH's uneven splits is split by object median from there on.
     template <typename EMIT>
     int32_t build(std::vector<wide_node>& nodes, build_prim* prims, uint32_t count,
-        uint32_t max_leaf, uint32_t depth, EMIT& emit_leaf, uint32_t& deepest) {
-        deepest = std::max(deepest, depth);
-        if (count <= max_leaf && (count == 1 || !worth_splitting(prims, count))) {
+        uint32_t max_leaf, uint32_t depth, uint32_t depth_limit, EMIT& emit_leaf,
+        uint32_t& deepest) {
+        if (count <= max_leaf &&
+            (count == 1 || depth >= depth_limit || !worth_splitting(prims, count))) {
             return encode_leaf(emit_leaf(prims, count), count);
         }
-        uint32_t const mid = partition(prims, count, depth);
+        if (depth >= depth_limit) {
+            throw std::runtime_error(
+                "accel: a mesh or the instance set is too large for the traversal stack");
+        }
+        deepest = std::max(deepest, depth + 1u);
+        uint32_t const levels_left = depth_limit - depth;
+        uint32_t const leaves = (count + max_leaf - 1u) / max_leaf;
+        uint32_t needed = 0;  // levels a balanced split needs: ceil(log2(leaves))
+        while ((1u << needed) < leaves) {
+            ++needed;
+        }
+        uint32_t const mid = partition(prims, count, needed + 1u >= levels_left);
         uint32_t const self = (uint32_t) nodes.size();
         nodes.push_back(wide_node{});
         box3 b0, b1;
@@ -79,9 +94,10 @@ public:
         for (uint32_t i = mid; i < count; ++i) {
             b1.grow(prims[i].bounds);
         }
-        int32_t const c0 = build(nodes, prims, mid, max_leaf, depth + 1, emit_leaf, deepest);
-        int32_t const c1 =
-            build(nodes, prims + mid, count - mid, max_leaf, depth + 1, emit_leaf, deepest);
+        int32_t const c0 =
+            build(nodes, prims, mid, max_leaf, depth + 1, depth_limit, emit_leaf, deepest);
+        int32_t const c1 = build(
+            nodes, prims + mid, count - mid, max_leaf, depth + 1, depth_limit, emit_leaf, deepest);
         wide_node& n = nodes[self];
         n.lo0x = b0.lo[0]; n.lo0y = b0.lo[1]; n.lo0z = b0.lo[2];
         n.hi0x = b0.hi[0]; n.hi0y = b0.hi[1]; n.hi0z = b0.hi[2];
@@ -169,8 +185,8 @@ private:
         return split_cost < kIntersectCost * (float) count;
     }
 
-    static uint32_t partition(build_prim* prims, uint32_t count, uint32_t depth) {
-        if (depth < kDepthLimit) {
+    static uint32_t partition(build_prim* prims, uint32_t count, bool force_median) {
+        if (!force_median) {
             split_choice const s = best_split(prims, count);
             if (s.axis >= 0) {
                 auto const it = std::partition(prims, prims + count, [&](build_prim const& p) {
@@ -225,57 +241,26 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
     out.tris.reserve(sc.triangle_count);
     tree_builder builder;
 
-    // One BLAS per mesh.
-    std::vector<int32_t> mesh_root(sc.mesh_count);
+    // Object-space bounds of every mesh.
     std::vector<box3> mesh_bounds(sc.mesh_count);
-    uint32_t deepest_blas = 0;
-    std::vector<build_prim> prims;
     for (uint32_t m = 0; m < sc.mesh_count; ++m) {
         rt_mesh const& mesh = sc.meshes[m];
         if (mesh.triangle_count == 0 ||
             (uint64_t) mesh.triangle_offset + mesh.triangle_count > sc.triangle_count) {
             throw std::runtime_error("accel: mesh triangle range out of bounds");
         }
-        prims.resize(mesh.triangle_count);
         for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
             rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
-            build_prim& p = prims[t];
-            p.bounds = box3{};
-            p.bounds.grow(tri.a.position_texu);
-            p.bounds.grow(tri.b.position_texu);
-            p.bounds.grow(tri.c.position_texu);
-            set_centroid(p);
-            p.id = mesh.triangle_offset + t;
-            mesh_bounds[m].grow(p.bounds);
+            mesh_bounds[m].grow(tri.a.position_texu);
+            mesh_bounds[m].grow(tri.b.position_texu);
+            mesh_bounds[m].grow(tri.c.position_texu);
         }
-        auto emit = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
-            uint32_t const first = (uint32_t) out.tris.size();
-            for (uint32_t i = 0; i < count; ++i) {
-                rt_triangle const& tri = sc.triangles[leaf[i].id];
-                tri_pos tp{};
-                tp.ax = tri.a.position_texu[0];
-                tp.ay = tri.a.position_texu[1];
-                tp.az = tri.a.position_texu[2];
-                tp.ref_index = leaf[i].id;
-                tp.bx = tri.b.position_texu[0];
-                tp.by = tri.b.position_texu[1];
-                tp.bz = tri.b.position_texu[2];
-                tp.cx = tri.c.position_texu[0];
-                tp.cy = tri.c.position_texu[1];
-                tp.cz = tri.c.position_texu[2];
-                out.tris.push_back(tp);
-            }
-            return first;
-        };
-        uint32_t deepest = 0;
-        mesh_root[m] = builder.build(
-            out.nodes, prims.data(), mesh.triangle_count, 4u, 0u, emit, deepest);
-        deepest_blas = std::max(deepest_blas, deepest);
     }
 
-    // TLAS over the world boxes of the instances (8 transformed corners of the
-    // mesh box, padded so rounding cannot cut a hit off).
-    prims.resize(sc.instance_count);
+    // TLAS first (its depth decides how deep the BLASes may be): world boxes of the
+    // instances = 8 transformed corners of the mesh box, padded so rounding cannot cut a
+    // hit off.
+    std::vector<build_prim> prims(sc.instance_count);
     for (uint32_t i = 0; i < sc.instance_count; ++i) {
         rt_instance const& inst = sc.instances[i];
         if (inst.mesh >= sc.mesh_count ||
@@ -323,14 +308,67 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
             rec.m[0] = rec.m[4] = rec.m[8] = 1.0f;
             rec.has_transform = 0;
         }
-        rec.blas_root = mesh_root[inst.mesh];
+        rec.blas_root = (int32_t) inst.mesh;  // replaced by the mesh's BLAS root below
         rec.ref_index = leaf[0].id;
         out.instances.push_back(rec);
         return first;
     };
+    // The stack holds TLAS siblings + one marker + BLAS siblings.  Leave the BLASes at
+    // least 12 levels (4 * 2^12 triangles balanced); the TLAS gets the rest at most.
+    uint32_t const tlas_limit = kStackEntries - 1u - 12u;
     uint32_t deepest_tlas = 0;
-    out.tlas_root = builder.build(
-        out.nodes, prims.data(), sc.instance_count, 1u, 0u, emit_instance, deepest_tlas);
+    out.tlas_root = builder.build(out.nodes, prims.data(), sc.instance_count, 1u, 0u, tlas_limit,
+        emit_instance, deepest_tlas);
+
+    // One BLAS per mesh, shared by its instances.
+    uint32_t const blas_limit = kStackEntries - 1u - deepest_tlas;
+    std::vector<int32_t> mesh_root(sc.mesh_count);
+    uint32_t deepest_blas = 0;
+    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
+        rt_mesh const& mesh = sc.meshes[m];
+        prims.resize(mesh.triangle_count);
+        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+            rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
+            build_prim& p = prims[t];
+            p.bounds = box3{};
+            p.bounds.grow(tri.a.position_texu);
+            p.bounds.grow(tri.b.position_texu);
+            p.bounds.grow(tri.c.position_texu);
+            set_centroid(p);
+            p.id = mesh.triangle_offset + t;
+        }
+        auto emit = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
+            uint32_t const first = (uint32_t) out.tris.size();
+            for (uint32_t i = 0; i < count; ++i) {
+                rt_triangle const& tri = sc.triangles[leaf[i].id];
+                tri_pos tp{};
+                tp.ax = tri.a.position_texu[0];
+                tp.ay = tri.a.position_texu[1];
+                tp.az = tri.a.position_texu[2];
+                tp.ref_index = leaf[i].id;
+                tp.bx = tri.b.position_texu[0];
+                tp.by = tri.b.position_texu[1];
+                tp.bz = tri.b.position_texu[2];
+                tp.cx = tri.c.position_texu[0];
+                tp.cy = tri.c.position_texu[1];
+                tp.cz = tri.c.position_texu[2];
+                out.tris.push_back(tp);
+            }
+            return first;
+        };
+        // Leaves of 4; meshes too large for the remaining levels get leaves of 8.
+        uint32_t leaf_size = 4u;
+        if (((uint64_t) leaf_size << (blas_limit > 1u ? blas_limit - 1u : 0u)) < mesh.triangle_count) {
+            leaf_size = 8u;
+        }
+        uint32_t deepest = 0;
+        mesh_root[m] = builder.build(out.nodes, prims.data(), mesh.triangle_count, leaf_size, 0u,
+            blas_limit, emit, deepest);
+        deepest_blas = std::max(deepest_blas, deepest);
+    }
+    for (instance_rec& rec : out.instances) {
+        rec.blas_root = mesh_root[(uint32_t) rec.blas_root];
+    }
     out.max_stack_bound = deepest_tlas + 1u + deepest_blas;
     return out;
 }

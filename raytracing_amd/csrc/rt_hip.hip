@@ -5,6 +5,7 @@
 // plain IEEE binary32 so results can be compared with the CPU oracle.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstring>
 #include <memory>
 #include <stdexcept>
@@ -23,7 +24,13 @@ using namespace rtd;
 namespace {
 
 // samples, closest, shadow, hits, nodes, tris, max_stack, shadow_skipped
+#ifdef RT_PHASE_TIMING
+// Diagnostic build: words 8.. hold per-wave cycle sums of the kernel's phases
+// (occlusion walks, closest-hit walks, everything else, whole wave).
+constexpr uint32_t kCounterWords = 16;
+#else
 constexpr uint32_t kCounterWords = 8;
+#endif
 constexpr uint32_t kPreviewRatio = 10; // src/renderer/megakernel_raytracer.cpp:54
 
 // Pixel owned by this lane: a wave covers one 8x8 pixel block of the rectangle.
@@ -34,31 +41,100 @@ constexpr uint32_t kPreviewRatio = 10; // src/renderer/megakernel_raytracer.cpp:
 // rays, and an expensive region of the image is shared by all XCDs instead of
 // leaving seven of them idle (contiguous per-XCD bands measured ~1.4 resident
 // waves per SIMD on average because of that tail).
-__device__ __forceinline__ bool lane_pixel(render_params const& p, uint32_t& x, uint32_t& y) {
+//
+// When the previous launch of the same frame left per-block costs behind
+// (render_params::block_order), blocks are instead taken most-expensive first:
+// the hardware hands the next workgroup to whichever slot frees up, so a
+// longest-first order keeps all slots busy until the very end (the cost of a
+// block barely changes from one launch to the next: same camera, same scene,
+// different random numbers).  `block` receives the linear block index.
+__device__ __forceinline__ bool lane_pixel(render_params const& p, uint32_t& x, uint32_t& y,
+    uint32_t& block) {
     uint32_t const blocks_x = (p.x1 - p.x0 + 7u) / 8u;
     uint32_t const blocks_y = (p.y1 - p.y0 + 7u) / 8u;
-    uint32_t const full_rows = blocks_y & ~7u;        // rows that interleave evenly
-    uint32_t const full_blocks = full_rows * blocks_x;
     uint32_t const i = blockIdx.x;
     uint32_t bx, by;
-    if (i < full_blocks) {
-        uint32_t const j = i / 8u;
-        bx = j % blocks_x;
-        by = (j / blocks_x) * 8u + (i % 8u);
+    if (p.block_order != nullptr) {
+        uint32_t const b = p.block_order[i];
+        bx = b % blocks_x;
+        by = b / blocks_x;
     } else {
-        uint32_t const t = i - full_blocks;
-        bx = t % blocks_x;
-        by = full_rows + t / blocks_x;
+        uint32_t const full_rows = blocks_y & ~7u;  // rows that interleave evenly
+        uint32_t const full_blocks = full_rows * blocks_x;
+        if (i < full_blocks) {
+            uint32_t const j = i / 8u;
+            bx = j % blocks_x;
+            by = (j / blocks_x) * 8u + (i % 8u);
+        } else {
+            uint32_t const t = i - full_blocks;
+            bx = t % blocks_x;
+            by = full_rows + t / blocks_x;
+        }
     }
+    block = by * blocks_x + bx;
     uint32_t const lane = threadIdx.x;
     x = p.x0 + bx * 8u + (lane & 7u);
     y = p.y0 + by * 8u + (lane >> 3);
     return x < p.x1 && y < p.y1;
 }
 
+// Turns the per-block costs of the launch that just finished into the block
+// order of the next one (descending cost), and clears the costs.  One
+// workgroup: a 256-bucket counting sort on cost relative to the maximum; the
+// order inside a bucket does not matter.
+constexpr uint32_t kOrderThreads = 1024;
+constexpr uint32_t kOrderBuckets = 256;
+
+__global__ void __launch_bounds__(kOrderThreads) order_blocks_kernel(uint32_t* cost,
+    uint32_t* order, uint32_t n) {
+    __shared__ uint32_t s_max;
+    __shared__ uint32_t s_count[kOrderBuckets];
+    __shared__ uint32_t s_start[kOrderBuckets];
+    uint32_t const tid = threadIdx.x;
+    if (tid == 0) {
+        s_max = 1u;
+    }
+    if (tid < kOrderBuckets) {
+        s_count[tid] = 0u;
+    }
+    __syncthreads();
+    uint32_t local_max = 0u;
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        local_max = max(local_max, cost[i]);
+    }
+    atomicMax(&s_max, local_max);
+    __syncthreads();
+    uint32_t const top = s_max;
+    auto bucket_of = [top](uint32_t c) -> uint32_t {
+        // bucket 0 = most expensive
+        uint32_t const q = (uint32_t) (((unsigned long long) c * (kOrderBuckets - 1u)) / top);
+        return (kOrderBuckets - 1u) - min(q, kOrderBuckets - 1u);
+    };
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        atomicAdd(&s_count[bucket_of(cost[i])], 1u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t running = 0u;
+        for (uint32_t b = 0; b < kOrderBuckets; ++b) {
+            s_start[b] = running;
+            running += s_count[b];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        uint32_t const slot = atomicAdd(&s_start[bucket_of(cost[i])], 1u);
+        order[slot] = i;
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += kOrderThreads) {
+        cost[i] = 0u;
+    }
+}
+
 // Second launch-bound argument = minimum waves per SIMD the register allocation must allow.
 #ifndef RT_WAVES_PER_SIMD
-#define RT_WAVES_PER_SIMD 4
+#define RT_WAVES_PER_SIMD 2
 #endif
 
 template <int ACCEL, bool COUNT>
@@ -67,10 +143,11 @@ __global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(rende
     fast_stack stk;
     stk.lds = lds_stack + threadIdx.x;
 
-    uint32_t x, y;
-    if (!lane_pixel(p, x, y)) {
+    uint32_t x, y, block;
+    if (!lane_pixel(p, x, y, block)) {
         return;
     }
+    unsigned long long const started = __builtin_readcyclecounter();
     scene_dev const& sc = p.sc;
     float* const px = p.accum + 4u * ((size_t) y * p.frame_width + x);
     f3 acc = splat3(0.0f);
@@ -90,6 +167,10 @@ __global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(rende
     // next bounce draws random numbers or adds to the radiance, so values and order of every
     // addition are those of the shader; only the surface state no longer has to stay alive
     // across a traversal.
+#ifdef RT_PHASE_TIMING
+    unsigned long long phase_shadow = 0, phase_closest = 0, phase_trips = 0;
+    unsigned long long phase_shadow_lanes = 0, phase_closest_lanes = 0;
+#endif
     uint32_t pass = 0;
     uint32_t seed;
     ray_pair rp;
@@ -106,7 +187,25 @@ __global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(rende
         pair_result pr;
         closest_rays += rp.has_closest ? 1u : 0u;
         shadow_rays += rp.has_shadow ? 1u : 0u;
+#ifdef RT_PHASE_TIMING
+        {
+            unsigned long long const t0 = __builtin_readcyclecounter();
+            hit_result unused;
+            pr.occluded = trace_fast<true, COUNT>(sc, stk, rp.has_shadow, rp.shadow_origin,
+                rp.shadow_direction, rp.shadow_t_max, unused, cnt);
+            unsigned long long const t1 = __builtin_readcyclecounter();
+            pr.hit = trace_fast<false, COUNT>(
+                sc, stk, rp.has_closest, rp.origin, rp.direction, kInfinity, pr.best, cnt);
+            unsigned long long const t2 = __builtin_readcyclecounter();
+            phase_shadow += t1 - t0;
+            phase_closest += t2 - t1;
+            phase_trips += 1;
+            phase_shadow_lanes += __builtin_popcountll(__ballot(rp.has_shadow));
+            phase_closest_lanes += __builtin_popcountll(__ballot(rp.has_closest));
+        }
+#else
         trace_pair<ACCEL, COUNT>(sc, stk, rp, pr, cnt);
+#endif
         if (rp.has_shadow && !pr.occluded) {
             radiance = radiance + nee;  // :547-549
         }
@@ -188,6 +287,21 @@ __global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(rende
     }
     *reinterpret_cast<float4*>(px) = make_float4(acc.x, acc.y, acc.z, 1.0f);
 
+#ifdef RT_PHASE_TIMING
+    if (p.counters && threadIdx.x == 0) {
+        atomicAdd(&p.counters[8], phase_shadow);
+        atomicAdd(&p.counters[9], phase_closest);
+        atomicAdd(&p.counters[10], (unsigned long long) (__builtin_readcyclecounter() - started));
+        atomicAdd(&p.counters[11], phase_trips);
+        atomicAdd(&p.counters[12], phase_shadow_lanes);
+        atomicAdd(&p.counters[13], phase_closest_lanes);
+    }
+#endif
+    if (p.block_cost) {
+        // how long this block's wave took: it orders the next launch (see lane_pixel)
+        unsigned long long const spent = __builtin_readcyclecounter() - started;
+        atomicMax(&p.block_cost[block], (uint32_t) min(spent, 0xFFFFFFFFull));
+    }
     if (p.counters) {
         // one atomic per lane and counter is plenty: this runs once per pixel per launch
         atomicAdd(&p.counters[0], (unsigned long long) p.pass_count);
@@ -208,8 +322,8 @@ __global__ void __launch_bounds__(64) primary_ids_kernel(render_params const p) 
     __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
     fast_stack stk;
     stk.lds = lds_stack + threadIdx.x;
-    uint32_t x, y;
-    if (!lane_pixel(p, x, y)) {
+    uint32_t x, y, block;
+    if (!lane_pixel(p, x, y, block)) {
         return;
     }
     uint32_t seed;
@@ -286,6 +400,13 @@ struct rt_hip_renderer {
     float* accum = nullptr;
     float* preview = nullptr;
     unsigned long long* counters = nullptr;
+
+    // cost feedback for full-frame launches (see lane_pixel / order_blocks_kernel)
+    uint32_t* block_cost = nullptr;
+    uint32_t* block_order = nullptr;
+    uint32_t block_total = 0;
+    bool order_valid = false;
+    rt_camera order_camera{};
 
     std::vector<void*> scene_allocs;
     scene_dev sc{};
@@ -466,8 +587,19 @@ void launch_rect(K kernel, render_params const& p, hipStream_t stream) {
     HIP_CHECK(hipGetLastError());
 }
 
-void launch_path_trace(rt_hip_renderer& r, render_params const& p, hipStream_t stream) {
+void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream) {
     bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
+    // Full-frame accumulation launches feed their per-block costs to the next one.
+    bool const whole_frame = !p.preview && p.x0 == 0 && p.y0 == 0 && p.x1 == r.cfg.width &&
+                             p.y1 == r.cfg.height && p.frame_width == r.cfg.width;
+    if (whole_frame) {
+        if (std::memcmp(&r.order_camera, &p.cam, sizeof(rt_camera)) != 0) {
+            r.order_valid = false;  // another view: yesterday's costs say nothing
+            r.order_camera = p.cam;
+        }
+        p.block_cost = r.block_cost;
+        p.block_order = r.order_valid ? r.block_order : nullptr;
+    }
     auto t = r.begin_timing(stream);
     if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
         if (count) {
@@ -483,6 +615,12 @@ void launch_path_trace(rt_hip_renderer& r, render_params const& p, hipStream_t s
         }
     }
     r.end_timing(t, stream);
+    if (whole_frame) {
+        hipLaunchKernelGGL(order_blocks_kernel, dim3(1), dim3(kOrderThreads), 0, stream,
+            r.block_cost, r.block_order, r.block_total);
+        HIP_CHECK(hipGetLastError());
+        r.order_valid = true;
+    }
 }
 
 render_params base_params(rt_hip_renderer const& r, rt_camera const& cam) {
@@ -567,6 +705,10 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         HIP_CHECK(hipMemset(r->accum, 0, accum_bytes));
         HIP_CHECK(hipMemset(r->preview, 0, preview_bytes));
         HIP_CHECK(hipMemset(r->counters, 0, kCounterWords * sizeof(unsigned long long)));
+        r->block_total = ((c.width + 7u) / 8u) * ((c.height + 7u) / 8u);
+        HIP_CHECK(hipMalloc((void**) &r->block_cost, r->block_total * sizeof(uint32_t)));
+        HIP_CHECK(hipMalloc((void**) &r->block_order, r->block_total * sizeof(uint32_t)));
+        HIP_CHECK(hipMemset(r->block_cost, 0, r->block_total * sizeof(uint32_t)));
         *out = r.release();
     });
 }
@@ -618,7 +760,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             }
         } else {
             built_accel const accel = build_wide_accel(s);
-            if (accel.max_stack_bound > kFastLdsEntries + kFastSpillEntries) {
+            if (accel.max_stack_bound > kFastLdsEntries) {
                 throw std::runtime_error("upload_scene: rebuilt BVH exceeds the traversal stack");
             }
             d.wide_nodes = r->upload(accel.nodes.data(), accel.nodes.size());
@@ -628,6 +770,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         }
         r->sc = d;
         r->scene_ready = true;
+        r->order_valid = false;
     });
 }
 
@@ -893,6 +1036,12 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
             out->shadow_skipped = words[7];
             out->seconds = r->seconds_total;
         }
+#ifdef RT_PHASE_TIMING
+        fprintf(stderr,
+            "phase cycles: shadow %llu closest %llu total %llu | wave trips %llu, lanes with "
+            "shadow ray %llu, with closest ray %llu\n",
+            words[8], words[9], words[10], words[11], words[12], words[13]);
+#endif
         if (reset) {
             HIP_CHECK(hipMemset(r->counters, 0, sizeof(words)));
             r->seconds_total = 0.0;
@@ -936,6 +1085,8 @@ int rt_hip_destroy(rt_hip_renderer* r) {
         (void) hipFree(r->accum);
         (void) hipFree(r->preview);
         (void) hipFree(r->counters);
+        (void) hipFree(r->block_cost);
+        (void) hipFree(r->block_order);
         (void) hipFree(r->seeds);
         delete r;
     });

@@ -31,6 +31,8 @@ struct render_params {
     uint32_t* out_triangle;
     float* out_t;
     float* out_bary;
+    const uint32_t* block_order;  // linear 8x8-block indices, most expensive first, or nullptr
+    uint32_t* block_cost;         // per-block cycle counts of this launch, or nullptr
 };
 
 // Traces a bounce's occlusion ray (optional) and the following closest-hit ray

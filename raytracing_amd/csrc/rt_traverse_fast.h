@@ -15,7 +15,7 @@
 //     shallow a ray visits only a handful of nodes, so serialised set-up
 //     would cost more than the walk itself;
 //   * the traversal stack lives in LDS (stack[entry][lane]: conflict-free for
-//     a wave), with a private overflow area that is essentially never used;
+//     a wave); the builder bounds the tree depth so it cannot overflow;
 //   * nearer child first by entry distance; the farther child is pushed and
 //     its own children are tested against the then-current t_max when popped.
 //
@@ -30,8 +30,11 @@
 
 namespace rtd {
 
-constexpr uint32_t kFastLdsEntries = 32;   // per-lane LDS stack entries
-constexpr uint32_t kFastSpillEntries = 64; // private overflow entries
+// Per-lane LDS stack entries.  The builder bounds the depth of its trees so that
+// TLAS depth + 1 (instance marker) + BLAS depth never exceeds this, which is why
+// there is no overflow path (a private overflow array would live in scratch
+// memory, and scratch-heavy kernels get fewer resident waves).
+constexpr uint32_t kFastLdsEntries = 32;
 constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
 
 struct fast_stack {
@@ -88,14 +91,9 @@ struct pair_result {
 template <bool ANY, bool COUNT>
 RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, f3 origin,
     f3 direction, float t_limit, hit_result& best, trace_counters& cnt) {
-    uint32_t spill[kFastSpillEntries];
     uint32_t sp = 0;
     auto push = [&](int32_t v) {
-        if (sp < kFastLdsEntries) {
-            stk.lds[sp * 64u] = (uint32_t) v;
-        } else if (sp - kFastLdsEntries < kFastSpillEntries) {
-            spill[sp - kFastLdsEntries] = (uint32_t) v;
-        }
+        stk.lds[(sp & (kFastLdsEntries - 1u)) * 64u] = (uint32_t) v;  // never wraps, see above
         ++sp;
         if (COUNT) {
             cnt.max_stack = max(cnt.max_stack, sp);
@@ -103,11 +101,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     };
     auto pop = [&]() -> int32_t {
         --sp;
-        if (sp < kFastLdsEntries) {
-            return (int32_t) stk.lds[sp * 64u];
-        }
-        uint32_t const i = sp - kFastLdsEntries;
-        return (int32_t) spill[i < kFastSpillEntries ? i : 0];
+        return (int32_t) stk.lds[(sp & (kFastLdsEntries - 1u)) * 64u];
     };
 
     float t_max = t_limit;
@@ -195,7 +189,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 }
             }
         }
-        // pop the next subtree
+        // pop the next subtree; leaving an instance restores the world-space ray
         for (;;) {
             if (sp == 0) {
                 return found;
