@@ -50,6 +50,8 @@ def parse_args():
     ap.add_argument("--max-depth", type=int, default=7)
     ap.add_argument("--spp-per-step", type=int, default=16)
     ap.add_argument("--accel", choices=["rebuilt", "reference"], default="rebuilt")
+    ap.add_argument("--pipeline", choices=["wavefront", "fused"], default="wavefront",
+                    help="trace/shade kernels per bounce (default) or the single fused kernel")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target duration of the CPU baseline sample")
@@ -109,8 +111,9 @@ def main():
     sc = scenes.load_snapshot(args.scene)
     cam = sc.camera(args.width, args.height)
     accel = hip.ACCEL_REBUILT if args.accel == "rebuilt" else hip.ACCEL_REFERENCE
+    flags = hip.FLAG_FUSED if args.pipeline == "fused" else hip.FLAG_TIME_KERNELS
     r = hip.HipRenderer(args.width, args.height, args.max_depth, tile, device=local_rank,
-                        accel=accel)
+                        accel=accel, flags=flags)
     r.upload_scene(sc.desc)
 
     spp = args.spp_per_step
@@ -163,17 +166,31 @@ def main():
             else None
         roofline = None
         if k is not None and launches > 0:
-            # per launch, this rank: rays counted on the device x the reference-BVH per-ray
-            # node/triangle counts measured by the oracle at this configuration
-            rays_l = (st["closest_rays"] + st["shadow_rays"]) / launches
-            bytes_l = (rays_l * (k["nodes_per_ray"] * NODE_BYTES + k["tris_per_ray"] * TRI_BYTES)
-                       + st["closest_hits"] / launches * HIT_BYTES
-                       + args.width * args.height * FRAME_BYTES)
-            achieved = bytes_l / (kernel_ms * 1e-3) / 1e9
+            # rays counted on the device x the reference-BVH per-ray node/triangle counts
+            # measured by the oracle at this configuration
+            trace_bytes = ((st["closest_rays"] + st["shadow_rays"])
+                           * (k["nodes_per_ray"] * NODE_BYTES + k["tris_per_ray"] * TRI_BYTES))
+            shade_bytes = st["closest_hits"] * HIT_BYTES
+            frame_bytes = args.width * args.height * FRAME_BYTES * launches
+            if args.pipeline == "fused":
+                name, ms, n = "path_trace_kernel", kernel_ms, launches
+                bytes_l = (trace_bytes + shade_bytes + frame_bytes) / n
+                extra = {}
+            else:
+                # the dominant kernel of the pipeline is the trace launch (one per bounce)
+                ms, n = r.kernel_time(hip.KERNEL_EXTEND)
+                shade_ms, shade_n = r.kernel_time(hip.KERNEL_SHADE)
+                name = "wf_extend_kernel"
+                bytes_l = trace_bytes / max(n, 1)
+                extra = {"render_call_avg_ms": kernel_ms, "render_calls": launches,
+                         "shade_kernel_avg_ms": shade_ms, "shade_launches": shade_n,
+                         "extend_ms_per_call": ms * n / launches,
+                         "shade_ms_per_call": shade_ms * shade_n / launches}
+            achieved = bytes_l / (ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                        "kernel": "path_trace_kernel", "kernel_avg_ms": kernel_ms,
-                        "launches": launches, "algorithmic_bytes_per_launch": bytes_l}
+                        "kernel": name, "kernel_avg_ms": ms, "launches": n,
+                        "algorithmic_bytes_per_launch": bytes_l, **extra}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             cpu = cpu_baseline(sc, cam, args, tile, args.cpu_seconds)
@@ -193,7 +210,7 @@ def main():
             "config": {
                 "workload": f"{args.scene} (reference scene, snapshot of its loader output), "
                             f"{args.width}x{args.height}, max_depth {args.max_depth}, "
-                            f"{spp} spp per step, accel={args.accel}",
+                            f"{spp} spp per step, accel={args.accel}, pipeline={args.pipeline}",
                 "samples_per_step_per_gpu": args.width * args.height * spp,
                 "parallelism": f"sample-range split x{world}, scene replicated, "
                                "one RCCL sum-reduce" if world > 1 else "single GPU",

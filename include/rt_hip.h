@@ -40,7 +40,22 @@ enum {
 };
 
 enum {
-    RT_HIP_FLAG_COUNT_NODES = 1u /* also count BVH nodes fetched / triangles tested */
+    RT_HIP_FLAG_COUNT_NODES = 1u, /* also count BVH nodes fetched / triangles tested */
+    /* rt_hip_render normally runs as a pipeline of small kernels (trace / shade per
+     * bounce, paths handed over through queues in device memory).  With this flag it
+     * runs as ONE kernel that keeps a path in registers from the first ray to the last,
+     * like the reference's shader; rt_hip_render_tile and rt_hip_render_preview always
+     * do.  Both give bit-identical images. */
+    RT_HIP_FLAG_FUSED = 2u,
+    /* Also time the pipeline's trace and shade launches one by one (two HIP events per
+     * launch); see rt_hip_kernel_time_of. */
+    RT_HIP_FLAG_TIME_KERNELS = 4u
+};
+
+enum {
+    RT_HIP_KERNEL_RENDER = 0, /* everything one rt_hip_render* call enqueues */
+    RT_HIP_KERNEL_EXTEND = 1, /* one trace launch of the pipeline (one bounce of a batch) */
+    RT_HIP_KERNEL_SHADE = 2   /* one shade launch of the pipeline */
 };
 
 #define RT_HIP_MISS 0xFFFFFFFFu
@@ -127,9 +142,15 @@ int rt_hip_set_passes(rt_hip_renderer* r, uint32_t passes);
  * recorded on the launch stream. */
 int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset);
 
-/* Average device time of the launches of the main kernel since the last
- * reset, in milliseconds, and how many launches that covers. */
+/* Average device time, in milliseconds, of what one rt_hip_render* call enqueues
+ * (from HIP events recorded on the launch stream) since the last reset of the
+ * statistics, and how many calls that covers. */
 int rt_hip_kernel_time(rt_hip_renderer* r, double* avg_ms, uint32_t* launches);
+
+/* The same for one kind of launch (RT_HIP_KERNEL_*).  The per-launch kinds are only
+ * recorded with RT_HIP_FLAG_TIME_KERNELS. */
+int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
+    uint32_t* launches);
 
 /* Replaces megakernel_raytracer_destroy (:793-813). */
 int rt_hip_destroy(rt_hip_renderer* r);

@@ -15,6 +15,7 @@
 #include "accel_build.h"
 #include "rt_hip.h"
 #include "rt_path.h"
+#include "rt_wavefront.h"
 
 using namespace rtd;
 
@@ -160,28 +161,18 @@ __global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(rende
     uint32_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, shadow_skipped = 0;
 
     // Each trip of the loop traces one ray pair - the previous bounce's occlusion ray, then
-    // this bounce's closest-hit ray - and shades the hit.  All shading of a bounce (light
-    // proposal, both BSDF evaluations, BSDF sampling) happens BEFORE its occlusion ray is
-    // traced: the next-event contribution is kept as three floats (`nee`) and added when the
-    // ray turns out unoccluded.  Nothing between the shader's occlusion test (:488) and the
-    // next bounce draws random numbers or adds to the radiance, so values and order of every
-    // addition are those of the shader; only the surface state no longer has to stay alive
-    // across a traversal.
-#ifdef RT_PHASE_TIMING
-    unsigned long long phase_shadow = 0, phase_closest = 0, phase_trips = 0;
-    unsigned long long phase_shadow_lanes = 0, phase_closest_lanes = 0;
-#endif
+    // this bounce's closest-hit ray - and shades the hit (shade_trip).
     uint32_t pass = 0;
-    uint32_t seed;
     ray_pair rp;
     rp.has_shadow = false;
     rp.has_closest = true;
-    f3 nee = splat3(0.0f);
-    f3 radiance = splat3(0.0f);
-    f3 throughput = splat3(1.0f);
-    float last_bsdf_pdf = 0.0f;
-    uint32_t depth = 0;
-    primary_ray(p, x, y, pass_seed(p, 0u, x, y), seed, rp.origin, rp.direction);
+    path_state ps;
+    ps.nee = splat3(0.0f);
+    ps.radiance = splat3(0.0f);
+    ps.throughput = splat3(1.0f);
+    ps.last_bsdf_pdf = 0.0f;
+    ps.depth = 0;
+    primary_ray(p, x, y, pass_seed(p, 0u, x, y), ps.seed, rp.origin, rp.direction);
 
     for (;;) {
         pair_result pr;
@@ -206,83 +197,19 @@ __global__ void __launch_bounds__(64, RT_WAVES_PER_SIMD) path_trace_kernel(rende
 #else
         trace_pair<ACCEL, COUNT>(sc, stk, rp, pr, cnt);
 #endif
-        if (rp.has_shadow && !pr.occluded) {
-            radiance = radiance + nee;  // :547-549
-        }
-        rp.has_shadow = false;
-        if (rp.has_closest) {
-            rp.has_closest = false;  // set again below when the path goes on
-            if (!pr.hit) {
-                // :518-527
-                f4 const ip = eval_sky_light(sc, rp.direction);
-                if (ip.w > 0.0f) {
-                    float const mis = depth > 0u ? power_heuristic(last_bsdf_pdf, ip.w) : 1.0f;
-                    radiance = radiance + (mk3(ip.x, ip.y, ip.z) * mis) * throughput;
-                }
-            } else {
-                ++closest_hits;
-                hit_state st;
-                fill_hit_state(sc, pr.best, rp.origin, rp.direction, st);
-                surface si;
-                make_surface(sc, st, si);
-                radiance = radiance + si.emission * throughput;
-                if (st.light < 0 && depth != p.max_depth) {
-                    lobe_mix const lm = make_lobe_mix(st, si, rp.direction);
-                    // state.glsl:14-16 - undoes the ray-facing flip, so the offset follows the
-                    // mesh's own normal direction even for back-face hits
-                    f3 const front_face_normal = st.front_face ? st.normal : -st.normal;
-                    f3 const shadow_origin = st.position + front_face_normal * kEpsilon;
-                    light_sample ls;
-                    bool const have_light =
-                        propose_light(sc, seed, rp.direction, shadow_origin, ls);
-                    f3 const next_direction = sample_disney(seed, st, si, lm);
-                    // One eval_disney body serves both uses (:541-550 and :554-560).
-#pragma nounroll
-                    for (int k = have_light ? 0 : 1; k < 2; ++k) {
-                        f3 const l = k == 0 ? ls.wi : next_direction;
-                        f4 const bsdf = eval_disney(st, si, lm, l);
-                        if (k == 0) {
-                            if (bsdf.w > 0.0f) {
-                                bool const is_delta = ls.type == RT_LIGHT_DISTANT;
-                                float const mis =
-                                    is_delta ? 1.0f : power_heuristic(ls.pdf, bsdf.w);
-                                f3 const f = mk3(bsdf.x, bsdf.y, bsdf.z);
-                                nee = (((f * mis) * ls.intensity) / ls.pdf) * throughput;
-                                rp.has_shadow = true;
-                                rp.shadow_origin = shadow_origin;
-                                rp.shadow_direction = ls.wi;
-                                rp.shadow_t_max = ls.shadow_t_max;
-                            } else {
-                                // the shader traces this occlusion ray and then discards the
-                                // sample (pdf <= 0): its outcome cannot reach the image
-                                ++shadow_skipped;
-                            }
-                        } else {
-                            last_bsdf_pdf = bsdf.w;
-                            if (bsdf.w > 0.0f) {
-                                throughput = throughput * (mk3(bsdf.x, bsdf.y, bsdf.z) / bsdf.w);
-                                rp.has_closest = true;
-                            }
-                        }
-                    }
-                    rp.direction = next_direction;
-                    rp.origin = st.position + next_direction * kEpsilon;
-                    ++depth;
-                }
-            }
-        }
+        shade_trip(sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
         if (!rp.has_closest && !rp.has_shadow) {
             // the path is over and its last occlusion ray is resolved
-            acc = p.preview ? radiance : acc + radiance;
+            acc = p.preview ? ps.radiance : acc + ps.radiance;
             ++pass;
             if (pass == p.pass_count) {
                 break;
             }
-            radiance = splat3(0.0f);
-            throughput = splat3(1.0f);
-            depth = 0;
+            ps.radiance = splat3(0.0f);
+            ps.throughput = splat3(1.0f);
+            ps.depth = 0;
             rp.has_closest = true;
-            primary_ray(p, x, y, pass_seed(p, pass, x, y), seed, rp.origin, rp.direction);
+            primary_ray(p, x, y, pass_seed(p, pass, x, y), ps.seed, rp.origin, rp.direction);
         }
     }
     *reinterpret_cast<float4*>(px) = make_float4(acc.x, acc.y, acc.z, 1.0f);
@@ -419,13 +346,21 @@ struct rt_hip_renderer {
     uint32_t passes_done = 0;
     uint32_t tile_cursor = 0;  // tiles dispatched in the current pass (render_tile cadence)
 
+    // wavefront pipeline state (allocated on first use, see launch_wavefront)
+    std::vector<void*> wf_allocs;
+    wavefront_params wf{};
+    size_t wf_paths = 0;
+    uint32_t wf_trips = 0;
+    uint32_t wf_extend_grid = 0, wf_shade_grid = 0;
+
     struct timed_launch {
         hipEvent_t start, stop;
+        uint32_t kind;  // RT_HIP_KERNEL_*
     };
     std::vector<timed_launch> launches;        // not yet folded into the totals
     std::vector<timed_launch> event_pool;      // reusable events
-    double seconds_total = 0.0;
-    uint32_t launches_total = 0;
+    double seconds_total[3] = {0.0, 0.0, 0.0};  // per RT_HIP_KERNEL_*
+    uint32_t launches_total[3] = {0, 0, 0};
 
     void use_device() const { HIP_CHECK(hipSetDevice(device)); }
 
@@ -455,7 +390,16 @@ struct rt_hip_renderer {
         scene_ready = false;
     }
 
-    timed_launch begin_timing(hipStream_t stream) {
+    void free_wavefront() {
+        for (void* p : wf_allocs) {
+            (void) hipFree(p);
+        }
+        wf_allocs.clear();
+        wf_paths = 0;
+        wf_trips = 0;
+    }
+
+    timed_launch begin_timing(hipStream_t stream, uint32_t kind = RT_HIP_KERNEL_RENDER) {
         timed_launch t{};
         if (!event_pool.empty()) {
             t = event_pool.back();
@@ -464,6 +408,7 @@ struct rt_hip_renderer {
             HIP_CHECK(hipEventCreate(&t.start));
             HIP_CHECK(hipEventCreate(&t.stop));
         }
+        t.kind = kind;
         HIP_CHECK(hipEventRecord(t.start, stream));
         return t;
     }
@@ -479,8 +424,8 @@ struct rt_hip_renderer {
             HIP_CHECK(hipEventSynchronize(t.stop));
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, t.start, t.stop));
-            seconds_total += (double) ms * 1e-3;
-            ++launches_total;
+            seconds_total[t.kind] += (double) ms * 1e-3;
+            ++launches_total[t.kind];
             event_pool.push_back(t);
         }
         launches.clear();
@@ -621,6 +566,181 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
         HIP_CHECK(hipGetLastError());
         r.order_valid = true;
     }
+}
+
+// Paths in flight per batch of the wavefront pipeline: 2^25 paths = 4.6 GB of state.
+constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 25;
+
+void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips) {
+    if (r.wf_extend_grid == 0) {
+        hipDeviceProp_t prop{};
+        HIP_CHECK(hipGetDeviceProperties(&prop, r.device));
+        uint32_t const cus = (uint32_t) std::max(1, prop.multiProcessorCount);
+        auto resident = [&](auto kernel) {
+            int per_cu = 0;
+            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0));
+            return cus * (uint32_t) std::max(1, per_cu);
+        };
+        bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
+        if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
+            r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true>)
+                                     : resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false>);
+        } else {
+            r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true>)
+                                     : resident(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false>);
+        }
+        r.wf_shade_grid = resident(wf_shade_kernel);
+        // per-wave work counters: allocated once, they outlive a regrowth of the state arrays
+        size_t const stat_bytes = (size_t) std::max(r.wf_extend_grid, r.wf_shade_grid) *
+                                  kStatWords * sizeof(unsigned long long);
+        HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
+        HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
+    }
+    if (paths <= r.wf_paths && trips <= r.wf_trips) {
+        return;
+    }
+    HIP_CHECK(hipDeviceSynchronize());
+    r.free_wavefront();
+    auto alloc = [&](size_t bytes) {
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, bytes));
+        r.wf_allocs.push_back(d);
+        return d;
+    };
+    wavefront_params& w = r.wf;
+    w.ray_o = (float4*) alloc(paths * 16);
+    w.ray_d = (float4*) alloc(paths * 16);
+    w.sh_o = (float4*) alloc(paths * 16);
+    w.sh_d = (float4*) alloc(paths * 16);
+    w.nee = (float4*) alloc(paths * 16);
+    w.thr = (float4*) alloc(paths * 16);
+    w.rad = (float4*) alloc(paths * 16);
+    w.hit0 = (float4*) alloc(paths * 16);
+    w.hit1 = (float2*) alloc(paths * 8);
+    w.occluded = (uint32_t*) alloc(paths * 4);
+    w.live = (uint32_t*) alloc(paths * 4);
+    w.q_closest = (uint32_t*) alloc(paths * 4);
+    w.q_shadow = (uint32_t*) alloc(paths * 4);
+    w.raw = (uint32_t*) alloc(paths * 4);
+    size_t const chunks = (paths + 63u) / 64u;
+    w.chunk_counts = (uint32_t*) alloc(chunks * 4);
+    w.tile_sums = (uint32_t*) alloc(((chunks + kTileChunks - 1u) / kTileChunks) * 12);
+    w.control = (uint32_t*) alloc((size_t) (trips + 1u) * kCtlWords * 4);
+    r.wf_paths = paths;
+    r.wf_trips = trips;
+}
+
+// rt_hip_render through the wavefront pipeline (rt_wavefront.h).
+void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t stream) {
+    uint32_t const blocks_x = (p.x1 - p.x0 + 7u) / 8u;
+    uint32_t const blocks_y = (p.y1 - p.y0 + 7u) / 8u;
+    size_t const per_pass = (size_t) blocks_x * blocks_y * 64u;
+    if (per_pass > kLivePidMask) {
+        throw std::runtime_error("render: rectangle too large for one batch");
+    }
+    static_assert(kWavefrontMaxPaths / 64u / kTileChunks <= kScanThreads,
+        "one workgroup must be able to scan the tile sums");
+    size_t const limit = std::min(kWavefrontMaxPaths, (size_t) kLivePidMask + 1u);
+    uint32_t const batch =
+        (uint32_t) std::min<size_t>(p.pass_count, std::max<size_t>(1, limit / per_pass));
+    uint32_t const trips = p.max_depth + 1u;
+    ensure_wavefront(r, per_pass * batch, trips);
+
+    wavefront_params w = r.wf;
+    w.sc = p.sc;
+    w.cam = p.cam;
+    w.accum = p.accum;
+    w.scalar_seed = p.scalar_seed;
+    w.frame_width = p.frame_width;
+    w.x0 = p.x0;
+    w.y0 = p.y0;
+    w.x1 = p.x1;
+    w.y1 = p.y1;
+    w.blocks_x = blocks_x;
+    w.block_count = blocks_x * blocks_y;
+    w.tile_width = p.tile_width;
+    w.tile_height = p.tile_height;
+    w.tiles_x = p.tiles_x;
+    w.tile_count = p.tile_count;
+    w.max_depth = p.max_depth;
+    w.preview = p.preview;
+    w.counters = p.counters;
+    bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
+    bool const each = (r.cfg.flags & RT_HIP_FLAG_TIME_KERNELS) != 0;
+
+    auto extend = [&](uint32_t trip, dim3 grid) {
+        if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
+            if (count) {
+                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true>), grid, dim3(64),
+                    0, stream, w, trip);
+            } else {
+                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false>), grid,
+                    dim3(64), 0, stream, w, trip);
+            }
+        } else {
+            if (count) {
+                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true>), grid, dim3(64),
+                    0, stream, w, trip);
+            } else {
+                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false>), grid, dim3(64),
+                    0, stream, w, trip);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+    };
+    // Builds trip `trip`'s lists from the raw slots its producer left behind.
+    auto compact = [&](uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count,
+                       uint32_t chunk_bound) {
+        dim3 const tiles(std::max(1u, (chunk_bound + kTileChunks - 1u) / kTileChunks));
+        hipLaunchKernelGGL(wf_tile_sums_kernel, tiles, dim3(kTileThreads), 0, stream, w,
+            in_count_ptr, in_count);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(wf_scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, stream, w, trip,
+            in_count_ptr, in_count);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(wf_scatter_kernel, tiles, dim3(kTileThreads), 0, stream, w,
+            in_count_ptr, in_count);
+        HIP_CHECK(hipGetLastError());
+    };
+
+    auto whole = r.begin_timing(stream);
+    for (uint32_t first = 0; first < p.pass_count; first += batch) {
+        w.pass_count = std::min(batch, p.pass_count - first);
+        w.seeds = p.seeds ? p.seeds + (size_t) first * p.tile_count : nullptr;
+        size_t const paths = per_pass * w.pass_count;
+        uint32_t const chunk_bound = (uint32_t) (paths / 64u);
+        hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t) ((paths + 255u) / 256u)), dim3(256),
+            0, stream, w);
+        HIP_CHECK(hipGetLastError());
+        compact(0, nullptr, (uint32_t) paths, chunk_bound);
+        for (uint32_t trip = 0; trip < trips; ++trip) {
+            // a trip has at most one closest-hit and one occlusion ray per path
+            dim3 const extend_grid(std::min(r.wf_extend_grid, 2u * chunk_bound));
+            dim3 const shade_grid(std::min(r.wf_shade_grid, chunk_bound));
+            rt_hip_renderer::timed_launch t{};
+            if (each) {
+                t = r.begin_timing(stream, RT_HIP_KERNEL_EXTEND);
+            }
+            extend(trip, extend_grid);
+            if (each) {
+                r.end_timing(t, stream);
+                t = r.begin_timing(stream, RT_HIP_KERNEL_SHADE);
+            }
+            hipLaunchKernelGGL(wf_shade_kernel, shade_grid, dim3(64), 0, stream, w, trip);
+            HIP_CHECK(hipGetLastError());
+            if (each) {
+                r.end_timing(t, stream);
+            }
+            if (trip + 1u < trips) {
+                // nothing survives the last trip: its paths are at max_depth
+                compact(trip + 1u, w.control + trip * kCtlWords + kCtlLive, 0u, chunk_bound);
+            }
+        }
+        hipLaunchKernelGGL(wf_resolve_kernel, dim3((uint32_t) ((per_pass + 255u) / 256u)),
+            dim3(256), 0, stream, w);
+        HIP_CHECK(hipGetLastError());
+    }
+    r.end_timing(whole, stream);
 }
 
 render_params base_params(rt_hip_renderer const& r, rt_camera const& cam) {
@@ -848,7 +968,11 @@ int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pa
         }
         p.pass_count = pass_count;
         p.seeds = r->seeds + (size_t) (first_pass - r->seeds_first_pass) * p.tile_count;
-        launch_path_trace(*r, p, (hipStream_t) stream);
+        if (r->cfg.flags & RT_HIP_FLAG_FUSED) {
+            launch_path_trace(*r, p, (hipStream_t) stream);
+        } else {
+            launch_wavefront(*r, p, (hipStream_t) stream);
+        }
         if (!accum_dev && !rect) {
             r->passes_done += pass_count;
         }
@@ -1025,6 +1149,25 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
         r->fold_timings();
         unsigned long long words[kCounterWords];
         HIP_CHECK(hipMemcpy(words, r->counters, sizeof(words), hipMemcpyDeviceToHost));
+        if (r->wf.wave_stats != nullptr) {
+            // the pipeline keeps its work counters per wave
+            size_t const waves = std::max(r->wf_extend_grid, r->wf_shade_grid);
+            std::vector<unsigned long long> per_wave(waves * kStatWords);
+            HIP_CHECK(hipMemcpy(per_wave.data(), r->wf.wave_stats,
+                per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+            for (size_t wv = 0; wv < waves; ++wv) {
+                unsigned long long const* s = &per_wave[wv * kStatWords];
+                words[3] += s[kStatClosestHits];
+                words[7] += s[kStatShadowSkipped];
+                words[4] += s[kStatNodes];
+                words[5] += s[kStatTris];
+                words[6] = std::max(words[6], s[kStatMaxStack]);
+            }
+            if (reset) {
+                HIP_CHECK(hipMemset(r->wf.wave_stats, 0,
+                    per_wave.size() * sizeof(unsigned long long)));
+            }
+        }
         if (out) {
             out->samples = words[0];
             out->closest_rays = words[1];
@@ -1034,7 +1177,7 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
             out->tris_tested = words[5];
             out->max_stack = words[6];
             out->shadow_skipped = words[7];
-            out->seconds = r->seconds_total;
+            out->seconds = r->seconds_total[RT_HIP_KERNEL_RENDER];
         }
 #ifdef RT_PHASE_TIMING
         fprintf(stderr,
@@ -1044,26 +1187,38 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
 #endif
         if (reset) {
             HIP_CHECK(hipMemset(r->counters, 0, sizeof(words)));
-            r->seconds_total = 0.0;
-            r->launches_total = 0;
+            for (int k = 0; k < 3; ++k) {
+                r->seconds_total[k] = 0.0;
+                r->launches_total[k] = 0;
+            }
+        }
+    });
+}
+
+int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
+    uint32_t* launches) {
+    return guarded([&] {
+        if (!r) {
+            throw std::runtime_error("null renderer");
+        }
+        if (kernel > RT_HIP_KERNEL_SHADE) {
+            throw std::runtime_error("kernel_time_of: unknown kernel");
+        }
+        r->use_device();
+        r->fold_timings();
+        if (avg_ms) {
+            *avg_ms = r->launches_total[kernel]
+                          ? r->seconds_total[kernel] * 1e3 / r->launches_total[kernel]
+                          : 0.0;
+        }
+        if (launches) {
+            *launches = r->launches_total[kernel];
         }
     });
 }
 
 int rt_hip_kernel_time(rt_hip_renderer* r, double* avg_ms, uint32_t* launches) {
-    return guarded([&] {
-        if (!r) {
-            throw std::runtime_error("null renderer");
-        }
-        r->use_device();
-        r->fold_timings();
-        if (avg_ms) {
-            *avg_ms = r->launches_total ? r->seconds_total * 1e3 / r->launches_total : 0.0;
-        }
-        if (launches) {
-            *launches = r->launches_total;
-        }
-    });
+    return rt_hip_kernel_time_of(r, RT_HIP_KERNEL_RENDER, avg_ms, launches);
 }
 
 int rt_hip_destroy(rt_hip_renderer* r) {
@@ -1074,6 +1229,8 @@ int rt_hip_destroy(rt_hip_renderer* r) {
         (void) hipSetDevice(r->device);
         (void) hipDeviceSynchronize();
         r->free_scene();
+        r->free_wavefront();
+        (void) hipFree(r->wf.wave_stats);
         for (auto& t : r->launches) {
             (void) hipEventDestroy(t.start);
             (void) hipEventDestroy(t.stop);

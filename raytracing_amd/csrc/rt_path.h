@@ -184,6 +184,95 @@ RT_DEV bool propose_light(scene_dev const& sc, uint32_t& seed, f3 ray_direction,
     return false;  // distant lights: the shader's branch is empty
 }
 
+// What a path carries from one bounce to the next.
+struct path_state {
+    f3 radiance;
+    f3 throughput;
+    f3 nee;               // next-event contribution waiting for its occlusion ray
+    float last_bsdf_pdf;
+    uint32_t depth;
+    uint32_t seed;
+};
+
+// One trip of the bounce loop (megakernel_raytracer.comp:509-565) after its rays have been
+// traced: `pr` holds the outcome of the previous bounce's occlusion ray and of this bounce's
+// closest-hit ray (`rp` says which of them existed).  All shading of a bounce (light
+// proposal, both BSDF evaluations, BSDF sampling) happens BEFORE its occlusion ray is traced:
+// the next-event contribution is kept as three floats (`nee`) and added when the ray turns
+// out unoccluded.  Nothing between the shader's occlusion test (:488) and the next bounce
+// draws random numbers or adds to the radiance, so values and order of every addition are
+// those of the shader; only the surface state no longer has to stay alive across a
+// traversal.  On return `rp` describes the next trip's rays; the path is over when it has
+// neither.
+RT_DEV void shade_trip(scene_dev const& sc, uint32_t max_depth, ray_pair& rp,
+    pair_result const& pr, path_state& ps, uint32_t& closest_hits, uint32_t& shadow_skipped) {
+    if (rp.has_shadow && !pr.occluded) {
+        ps.radiance = ps.radiance + ps.nee;  // :547-549
+    }
+    rp.has_shadow = false;
+    if (rp.has_closest) {
+        rp.has_closest = false;  // set again below when the path goes on
+        if (!pr.hit) {
+            // :518-527
+            f4 const ip = eval_sky_light(sc, rp.direction);
+            if (ip.w > 0.0f) {
+                float const mis = ps.depth > 0u ? power_heuristic(ps.last_bsdf_pdf, ip.w) : 1.0f;
+                ps.radiance = ps.radiance + (mk3(ip.x, ip.y, ip.z) * mis) * ps.throughput;
+            }
+        } else {
+            ++closest_hits;
+            hit_state st;
+            fill_hit_state(sc, pr.best, rp.origin, rp.direction, st);
+            surface si;
+            make_surface(sc, st, si);
+            ps.radiance = ps.radiance + si.emission * ps.throughput;
+            if (st.light < 0 && ps.depth != max_depth) {
+                lobe_mix const lm = make_lobe_mix(st, si, rp.direction);
+                // state.glsl:14-16 - undoes the ray-facing flip, so the offset follows the
+                // mesh's own normal direction even for back-face hits
+                f3 const front_face_normal = st.front_face ? st.normal : -st.normal;
+                f3 const shadow_origin = st.position + front_face_normal * kEpsilon;
+                light_sample ls;
+                bool const have_light =
+                    propose_light(sc, ps.seed, rp.direction, shadow_origin, ls);
+                f3 const next_direction = sample_disney(ps.seed, st, si, lm);
+                // One eval_disney body serves both uses (:541-550 and :554-560).
+#pragma nounroll
+                for (int k = have_light ? 0 : 1; k < 2; ++k) {
+                    f3 const l = k == 0 ? ls.wi : next_direction;
+                    f4 const bsdf = eval_disney(st, si, lm, l);
+                    if (k == 0) {
+                        if (bsdf.w > 0.0f) {
+                            bool const is_delta = ls.type == RT_LIGHT_DISTANT;
+                            float const mis =
+                                is_delta ? 1.0f : power_heuristic(ls.pdf, bsdf.w);
+                            f3 const f = mk3(bsdf.x, bsdf.y, bsdf.z);
+                            ps.nee = (((f * mis) * ls.intensity) / ls.pdf) * ps.throughput;
+                            rp.has_shadow = true;
+                            rp.shadow_origin = shadow_origin;
+                            rp.shadow_direction = ls.wi;
+                            rp.shadow_t_max = ls.shadow_t_max;
+                        } else {
+                            // the shader traces this occlusion ray and then discards the
+                            // sample (pdf <= 0): its outcome cannot reach the image
+                            ++shadow_skipped;
+                        }
+                    } else {
+                        ps.last_bsdf_pdf = bsdf.w;
+                        if (bsdf.w > 0.0f) {
+                            ps.throughput = ps.throughput * (mk3(bsdf.x, bsdf.y, bsdf.z) / bsdf.w);
+                            rp.has_closest = true;
+                        }
+                    }
+                }
+                rp.direction = next_direction;
+                rp.origin = st.position + next_direction * kEpsilon;
+                ++ps.depth;
+            }
+        }
+    }
+}
+
 // Seeds a pixel for one pass and builds its jittered primary ray
 // (megakernel_raytracer.comp:85-100).
 RT_DEV void primary_ray(render_params const& p, uint32_t x, uint32_t y, uint32_t random_seed,

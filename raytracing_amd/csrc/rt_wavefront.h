@@ -1,0 +1,525 @@
+// Wavefront form of the path tracer: the bounce loop of megakernel_raytracer.comp:509-565
+// cut into small kernels that hand paths to each other through queues in HBM.
+//
+// Why: the fused kernel needs ~200 VGPRs (the Disney BSDF), which leaves two waves per SIMD,
+// and traversal is a chain of dependent loads - it runs at the speed of memory latency
+// divided by the number of resident waves.  The traversal kernel alone fits in well under
+// 100 VGPRs, so five waves per SIMD hide that latency, and because it pulls rays from a
+// compacted queue every lane of a wave has a ray (in the fused kernel only about half the
+// lanes have an occlusion ray to trace).
+//
+// All paths of a batch of passes are in flight at once.  Path `pid` = (pass, 8x8 pixel
+// block, lane) owns slot `pid` of every state array for its whole life; queues carry pids.
+// One trip = one `extend` launch (trace the previous bounce's occlusion ray and this
+// bounce's closest-hit ray of every live path) + one `shade` launch (shade_trip, the same
+// function the fused kernel calls).  Finished paths leave their radiance in `rad[pid]`;
+// `resolve` adds a pixel's passes in pass order, so the image is bit-identical to the
+// reference's one-dispatch-per-pass accumulation.
+//
+// No queue is filled through an atomic counter: tens of thousands of waves adding to one
+// address serialise (measured: ~7.5 ns per atomic, more than the shading itself).  Instead
+// a producer writes one word per input slot ("raw": the surviving path with its ray flags,
+// or 0) plus one packed count per 64 slots; a scan turns the counts into offsets and a
+// scatter kernel writes the compacted lists.  The lists therefore keep pid
+// order from trip to trip - neighbouring pixels stay neighbours, which keeps the state
+// arrays' accesses coalesced and the rays of a wave coherent - and a render is
+// reproducible down to the order of its memory accesses.
+//
+// The per-trip kernels run on a fixed grid of resident waves; wave w takes chunks w, w + W,
+// w + 2W ... (list lengths exist only on the device).  Work counters are kept per wave
+// (wave_stats) and summed when they are read.
+#pragma once
+
+#include "rt_path.h"
+
+namespace rtd {
+
+// Words of the per-trip control block.
+enum : uint32_t {
+    kCtlLive = 0,     // entries in this trip's live list
+    kCtlClosest = 1,  // entries in this trip's closest-hit ray queue
+    kCtlShadow = 2,   // entries in this trip's occlusion ray queue
+    kCtlWords = 4,
+};
+
+// Per-wave work counters (wave_stats[slot][k]); slot = wave index in its launch.
+enum : uint32_t {
+    kStatClosestHits = 1,
+    kStatShadowSkipped = 2,
+    kStatNodes = 3,
+    kStatTris = 4,
+    kStatMaxStack = 5,
+    kStatWords = 8,
+};
+constexpr uint32_t kScanThreads = 1024;
+
+// Live-list entry = pid | flags.
+constexpr uint32_t kLiveHasShadow = 0x40000000u;
+constexpr uint32_t kLiveHasClosest = 0x80000000u;
+constexpr uint32_t kLivePidMask = 0x3FFFFFFFu;
+
+struct wavefront_params {
+    scene_dev sc;
+    rt_camera cam;
+    // path state, one slot per pid
+    float4* ray_o;     // closest-hit ray origin
+    float4* ray_d;     // closest-hit ray direction
+    float4* sh_o;      // occlusion ray origin, w = t_max
+    float4* sh_d;      // occlusion ray direction
+    float4* nee;       // pending next-event contribution, w = last BSDF pdf
+    float4* thr;       // throughput, w = random seed bits
+    float4* rad;       // radiance so far (final when the path is over), w = depth bits
+    float4* hit0;      // instance bits, triangle bits, b0, b1   (instance = RT_HIP_MISS: no hit)
+    float2* hit1;      // b2, t
+    uint32_t* occluded;  // outcome of the occlusion ray
+    uint32_t* live;          // compacted: pid | flags of every path with a ray this trip
+    uint32_t* q_closest;     // compacted pids with a closest-hit ray
+    uint32_t* q_shadow;      // compacted pids with an occlusion ray
+    uint32_t* raw;           // per input slot: pid | flags of the surviving path, or 0
+    uint32_t* chunk_counts;  // per 64 raw slots: live | closest << 8 | shadow << 16
+    uint32_t* tile_sums;     // per 1024 chunks: 3 words, sums and then offsets of the tile
+    uint32_t* control;       // [trip][kCtlWords]
+    unsigned long long* wave_stats;  // [wave][kStatWords]
+    unsigned long long* counters;    // closest / occlusion ray totals (one add per launch)
+    // frame
+    float* accum;
+    const uint32_t* seeds;  // [pass][tile] of this batch, or nullptr -> scalar_seed
+    uint32_t scalar_seed;
+    uint32_t frame_width;
+    uint32_t x0, y0, x1, y1;
+    uint32_t blocks_x, block_count;  // 8x8 blocks covering the rectangle
+    uint32_t tile_width, tile_height, tiles_x, tile_count;
+    uint32_t pass_count;             // passes in this batch
+    uint32_t max_depth;
+    uint32_t preview;
+};
+
+RT_DEV uint32_t wave_lane() { return threadIdx.x & 63u; }
+
+// Index of this wave in its launch and the number of waves launched.
+RT_DEV uint32_t wave_index() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
+RT_DEV uint32_t wave_total() { return (gridDim.x * blockDim.x) >> 6; }
+
+// Publishes one raw slot per lane and the chunk's packed counts.
+RT_DEV void publish_raw(wavefront_params const& p, uint32_t chunk, uint32_t slot, bool in_range,
+    uint32_t entry) {
+    unsigned long long const live = __ballot(entry != 0u);
+    unsigned long long const closest = __ballot((entry & kLiveHasClosest) != 0u);
+    unsigned long long const shadow = __ballot((entry & kLiveHasShadow) != 0u);
+    if (in_range) {
+        p.raw[slot] = entry;
+    }
+    if (wave_lane() == 0) {
+        p.chunk_counts[chunk] = (uint32_t) __builtin_popcountll(live) |
+                                ((uint32_t) __builtin_popcountll(closest) << 8) |
+                                ((uint32_t) __builtin_popcountll(shadow) << 16);
+    }
+}
+
+RT_DEV void add_wave_stat(wavefront_params const& p, uint32_t k, unsigned long long v) {
+    // one lane per wave, no other wave touches this slot
+    unsigned long long* const slot = p.wave_stats + (size_t) wave_index() * kStatWords + k;
+    *slot += v;
+}
+
+RT_DEV unsigned long long wave_sum(uint32_t v) {
+    unsigned long long total = 0;
+    for (int offset = 32; offset > 0; offset >>= 1) {
+        v += (uint32_t) __shfl_down((int) v, offset, 64);
+    }
+    total = (unsigned long long) (uint32_t) __builtin_amdgcn_readfirstlane((int) v);
+    return total;
+}
+
+RT_DEV bool pid_pixel(wavefront_params const& p, uint32_t pid, uint32_t& x, uint32_t& y,
+    uint32_t& pass) {
+    uint32_t const per_pass = p.block_count * 64u;
+    pass = pid / per_pass;
+    uint32_t const in_pass = pid - pass * per_pass;
+    uint32_t const block = in_pass >> 6;
+    uint32_t const lane = in_pass & 63u;
+    x = p.x0 + (block % p.blocks_x) * 8u + (lane & 7u);
+    y = p.y0 + (block / p.blocks_x) * 8u + (lane >> 3);
+    return x < p.x1 && y < p.y1;
+}
+
+// Starts every path of the batch: seeds it, builds its primary ray
+// (megakernel_raytracer.comp:85-100) and publishes it as raw slot `pid`.
+__global__ void __launch_bounds__(256) wf_generate_kernel(wavefront_params const p) {
+    uint32_t const pid = blockIdx.x * 256u + threadIdx.x;
+    uint32_t const paths = p.pass_count * p.block_count * 64u;  // a multiple of 64
+    uint32_t x, y, pass;
+    bool const valid = pid < paths && pid_pixel(p, pid, x, y, pass);
+    if (valid) {
+        uint32_t random_seed = p.scalar_seed;
+        if (p.seeds != nullptr) {
+            uint32_t const tile = (y / p.tile_height) * p.tiles_x + x / p.tile_width;
+            random_seed = p.seeds[(size_t) pass * p.tile_count + tile];
+        }
+        f3 const du = load3(p.cam.pixel_delta_u);
+        f3 const dv = load3(p.cam.pixel_delta_v);
+        f3 const ul = load3(p.cam.upper_left_pixel);
+        f3 const pos = load3(p.cam.position);
+        uint32_t seed = hash_combine(random_seed, p.frame_width * y + x);
+        f3 const pixel = (ul + du * (float) (int) x) + dv * (float) (int) y;
+        float const ox = -0.5f + rand_01(seed);
+        float const oy = -0.5f + rand_01(seed);
+        f3 const pixel_sample = pixel + (du * ox + dv * oy);
+        f3 const direction = normalize3(pixel_sample - pos);
+        p.ray_o[pid] = make_float4(pos.x, pos.y, pos.z, 0.0f);
+        p.ray_d[pid] = make_float4(direction.x, direction.y, direction.z, 0.0f);
+        p.nee[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        p.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(seed));
+        p.rad[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    }
+    if (pid < paths) {  // whole waves: paths is a multiple of 64
+        publish_raw(p, pid >> 6, pid, true, valid ? (pid | kLiveHasClosest) : 0u);
+    }
+}
+
+// Compaction of the raw slots into trip `trip`'s lists, in three small launches over tiles of
+// kTileChunks chunks: (1) per-tile sums of the packed chunk counts, (2) one workgroup scans
+// the tile sums and records the list lengths, (3) every tile scans its own chunk counts and
+// scatters its survivors.  `in_count_ptr ? *in_count_ptr : in_count` = number of raw slots.
+constexpr uint32_t kTileChunks = 1024;
+constexpr uint32_t kTileThreads = 1024;
+
+struct triple {
+    uint32_t live, closest, shadow;
+};
+
+RT_DEV triple unpack_counts(uint32_t packed) {
+    return triple{packed & 0xFFu, (packed >> 8) & 0xFFu, (packed >> 16) & 0xFFu};
+}
+
+// Inclusive scan of one value per thread over a workgroup of THREADS threads.
+template <uint32_t THREADS>
+RT_DEV triple block_inclusive_scan(triple v, uint32_t (*scratch)[THREADS]) {
+    uint32_t const t = threadIdx.x;
+    scratch[0][t] = v.live;
+    scratch[1][t] = v.closest;
+    scratch[2][t] = v.shadow;
+    __syncthreads();
+    for (uint32_t step = 1; step < THREADS; step <<= 1) {
+        triple add{0u, 0u, 0u};
+        if (t >= step) {
+            add = triple{scratch[0][t - step], scratch[1][t - step], scratch[2][t - step]};
+        }
+        __syncthreads();
+        scratch[0][t] += add.live;
+        scratch[1][t] += add.closest;
+        scratch[2][t] += add.shadow;
+        __syncthreads();
+    }
+    return triple{scratch[0][t], scratch[1][t], scratch[2][t]};
+}
+
+__global__ void __launch_bounds__(kTileThreads) wf_tile_sums_kernel(wavefront_params const p,
+    const uint32_t* in_count_ptr, uint32_t in_count) {
+    __shared__ uint32_t scratch[3][kTileThreads];
+    uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
+    uint32_t const chunks = (n + 63u) / 64u;
+    uint32_t const first = blockIdx.x * kTileChunks;
+    if (first >= chunks) {
+        return;
+    }
+    triple sum{0u, 0u, 0u};
+    for (uint32_t c = first + threadIdx.x; c < min(first + kTileChunks, chunks);
+         c += kTileThreads) {
+        triple const v = unpack_counts(p.chunk_counts[c]);
+        sum.live += v.live;
+        sum.closest += v.closest;
+        sum.shadow += v.shadow;
+    }
+    triple const total = block_inclusive_scan<kTileThreads>(sum, scratch);
+    if (threadIdx.x == kTileThreads - 1u) {
+        p.tile_sums[3u * blockIdx.x + 0u] = total.live;
+        p.tile_sums[3u * blockIdx.x + 1u] = total.closest;
+        p.tile_sums[3u * blockIdx.x + 2u] = total.shadow;
+    }
+}
+
+__global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_params const p,
+    uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count) {
+    __shared__ uint32_t scratch[3][kScanThreads];
+    uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
+    uint32_t const chunks = (n + 63u) / 64u;
+    uint32_t const tiles = (chunks + kTileChunks - 1u) / kTileChunks;  // <= kScanThreads
+    uint32_t const t = threadIdx.x;
+    triple mine{0u, 0u, 0u};
+    if (t < tiles) {
+        mine = triple{p.tile_sums[3u * t], p.tile_sums[3u * t + 1u], p.tile_sums[3u * t + 2u]};
+    }
+    triple const incl = block_inclusive_scan<kScanThreads>(mine, scratch);
+    if (t < tiles) {
+        p.tile_sums[3u * t + 0u] = incl.live - mine.live;  // exclusive: the tile's offsets
+        p.tile_sums[3u * t + 1u] = incl.closest - mine.closest;
+        p.tile_sums[3u * t + 2u] = incl.shadow - mine.shadow;
+    }
+    if (t == kScanThreads - 1u) {
+        uint32_t* const ctl = p.control + trip * kCtlWords;
+        ctl[kCtlLive] = incl.live;
+        ctl[kCtlClosest] = incl.closest;
+        ctl[kCtlShadow] = incl.shadow;
+        // single thread of a single workgroup, launches of one renderer are stream-ordered
+        if (trip == 0u) {
+            p.counters[0] += incl.live;  // every path of the batch starts in trip 0
+        }
+        p.counters[1] += incl.closest;
+        p.counters[2] += incl.shadow;
+    }
+}
+
+__global__ void __launch_bounds__(kTileThreads) wf_scatter_kernel(wavefront_params const p,
+    const uint32_t* in_count_ptr, uint32_t in_count) {
+    __shared__ uint32_t scratch[3][kTileThreads];
+    __shared__ uint32_t base[3][kTileChunks];
+    uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
+    uint32_t const chunks = (n + 63u) / 64u;
+    uint32_t const first = blockIdx.x * kTileChunks;
+    if (first >= chunks) {
+        return;
+    }
+    // thread t owns chunks first + 4t .. first + 4t + 3
+    constexpr uint32_t kPerThread = kTileChunks / kTileThreads;
+    triple own[kPerThread];
+    triple sum{0u, 0u, 0u};
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        uint32_t const c = first + threadIdx.x * kPerThread + k;
+        own[k] = c < chunks ? unpack_counts(p.chunk_counts[c]) : triple{0u, 0u, 0u};
+        sum.live += own[k].live;
+        sum.closest += own[k].closest;
+        sum.shadow += own[k].shadow;
+    }
+    triple const incl = block_inclusive_scan<kTileThreads>(sum, scratch);
+    triple run{p.tile_sums[3u * blockIdx.x + 0u] + incl.live - sum.live,
+        p.tile_sums[3u * blockIdx.x + 1u] + incl.closest - sum.closest,
+        p.tile_sums[3u * blockIdx.x + 2u] + incl.shadow - sum.shadow};
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        uint32_t const c = threadIdx.x * kPerThread + k;
+        base[0][c] = run.live;
+        base[1][c] = run.closest;
+        base[2][c] = run.shadow;
+        run.live += own[k].live;
+        run.closest += own[k].closest;
+        run.shadow += own[k].shadow;
+    }
+    __syncthreads();
+    unsigned long long const below = (1ull << wave_lane()) - 1ull;
+    uint32_t const wave_in_block = threadIdx.x >> 6;
+    for (uint32_t c = wave_in_block; c < kTileChunks && first + c < chunks;
+         c += kTileThreads / 64u) {
+        uint32_t const slot = (first + c) * 64u + wave_lane();
+        uint32_t const entry = slot < n ? p.raw[slot] : 0u;
+        bool const has_closest = (entry & kLiveHasClosest) != 0u;
+        bool const has_shadow = (entry & kLiveHasShadow) != 0u;
+        unsigned long long const live = __ballot(entry != 0u);
+        unsigned long long const closest = __ballot(has_closest);
+        unsigned long long const shadow = __ballot(has_shadow);
+        if (entry != 0u) {
+            p.live[base[0][c] + (uint32_t) __builtin_popcountll(live & below)] = entry;
+        }
+        if (has_closest) {
+            p.q_closest[base[1][c] + (uint32_t) __builtin_popcountll(closest & below)] =
+                entry & kLivePidMask;
+        }
+        if (has_shadow) {
+            p.q_shadow[base[2][c] + (uint32_t) __builtin_popcountll(shadow & below)] =
+                entry & kLivePidMask;
+        }
+    }
+}
+
+// Traces every ray of trip `trip`: chunks [0, closest_chunks) hold closest-hit rays, the
+// rest occlusion rays, so a wave never mixes the two kinds.
+template <int ACCEL, bool COUNT>
+__global__ void __launch_bounds__(64, ACCEL == RT_HIP_ACCEL_REBUILT ? 5 : 2)
+    wf_extend_kernel(wavefront_params const p, uint32_t trip) {
+    __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
+    fast_stack stk;
+    stk.lds = lds_stack + threadIdx.x;
+    const uint32_t* const ctl = p.control + trip * kCtlWords;
+    uint32_t const n_closest = ctl[kCtlClosest];
+    uint32_t const n_shadow = ctl[kCtlShadow];
+    uint32_t const closest_chunks = (n_closest + 63u) / 64u;
+    uint32_t const total_chunks = closest_chunks + (n_shadow + 63u) / 64u;
+    const uint32_t* const q_closest = p.q_closest;
+    const uint32_t* const q_shadow = p.q_shadow;
+    trace_counters cnt;
+    for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
+        if (chunk < closest_chunks) {
+            uint32_t const i = chunk * 64u + wave_lane();
+            bool const active = i < n_closest;
+            uint32_t const pid = active ? q_closest[i] : 0u;
+            float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            if (active) {
+                o = p.ray_o[pid];
+                d = p.ray_d[pid];
+            }
+            hit_result best;
+            best.instance = RT_HIP_MISS;
+            best.triangle = RT_HIP_MISS;
+            best.b0 = best.b1 = best.b2 = 0.0f;
+            best.t = kInfinity;
+            bool hit;
+            if (ACCEL == RT_HIP_ACCEL_REBUILT) {
+                hit = trace_fast<false, COUNT>(p.sc, stk, active, mk3(o.x, o.y, o.z),
+                    mk3(d.x, d.y, d.z), kInfinity, best, cnt);
+            } else {
+                hit = active && trace_ref<false, COUNT>(p.sc, mk3(o.x, o.y, o.z),
+                                    mk3(d.x, d.y, d.z), kInfinity, best, cnt);
+            }
+            if (active) {
+                p.hit0[pid] = make_float4(__uint_as_float(hit ? best.instance : RT_HIP_MISS),
+                    __uint_as_float(best.triangle), best.b0, best.b1);
+                p.hit1[pid] = make_float2(best.b2, best.t);
+            }
+        } else {
+            uint32_t const i = (chunk - closest_chunks) * 64u + wave_lane();
+            bool const active = i < n_shadow;
+            uint32_t const pid = active ? q_shadow[i] : 0u;
+            float4 o = make_float4(0.0f, 0.0f, 0.0f, 1.0f), d = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            if (active) {
+                o = p.sh_o[pid];
+                d = p.sh_d[pid];
+            }
+            hit_result unused;
+            bool blocked;
+            if (ACCEL == RT_HIP_ACCEL_REBUILT) {
+                blocked = trace_fast<true, COUNT>(p.sc, stk, active, mk3(o.x, o.y, o.z),
+                    mk3(d.x, d.y, d.z), o.w, unused, cnt);
+            } else {
+                blocked = active && trace_ref<true, COUNT>(p.sc, mk3(o.x, o.y, o.z),
+                                        mk3(d.x, d.y, d.z), o.w, unused, cnt);
+            }
+            if (active) {
+                p.occluded[pid] = blocked ? 1u : 0u;
+            }
+        }
+    }
+    if (COUNT) {
+        unsigned long long const nodes = wave_sum(cnt.nodes);
+        unsigned long long const tris = wave_sum(cnt.tris);
+        uint32_t deepest = cnt.max_stack;
+        for (int offset = 32; offset > 0; offset >>= 1) {
+            deepest = max(deepest, (uint32_t) __shfl_down((int) deepest, offset, 64));
+        }
+        if (wave_lane() == 0) {
+            add_wave_stat(p, kStatNodes, nodes);
+            add_wave_stat(p, kStatTris, tris);
+            unsigned long long* const slot =
+                p.wave_stats + (size_t) wave_index() * kStatWords + kStatMaxStack;
+            *slot = max(*slot, (unsigned long long) deepest);
+        }
+    }
+}
+
+// Shades every live path of trip `trip`; survivors are published as raw slots for the
+// compaction that builds trip + 1's lists.
+__global__ void __launch_bounds__(64, 2) wf_shade_kernel(wavefront_params const p, uint32_t trip) {
+    uint32_t const n_live = p.control[trip * kCtlWords + kCtlLive];
+    uint32_t const total_chunks = (n_live + 63u) / 64u;
+    const uint32_t* const live = p.live;
+    uint32_t total_hits = 0, total_skipped = 0;
+    for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
+        uint32_t const i = chunk * 64u + wave_lane();
+        bool const active = i < n_live;
+        uint32_t const entry = active ? live[i] : 0u;
+        uint32_t const pid = entry & kLivePidMask;
+        ray_pair rp;
+        rp.has_shadow = (entry & kLiveHasShadow) != 0u;
+        rp.has_closest = (entry & kLiveHasClosest) != 0u;
+        uint32_t closest_hits = 0, shadow_skipped = 0;
+        if (active) {
+            float4 const rad = p.rad[pid];
+            float4 const thr = p.thr[pid];
+            float4 const nee = p.nee[pid];
+            path_state ps;
+            ps.radiance = mk3(rad.x, rad.y, rad.z);
+            ps.depth = __float_as_uint(rad.w);
+            ps.throughput = mk3(thr.x, thr.y, thr.z);
+            ps.seed = __float_as_uint(thr.w);
+            ps.nee = mk3(nee.x, nee.y, nee.z);
+            ps.last_bsdf_pdf = nee.w;
+            pair_result pr;
+            pr.occluded = rp.has_shadow && p.occluded[pid] != 0u;
+            pr.hit = false;
+            if (rp.has_closest) {
+                float4 const o = p.ray_o[pid];
+                float4 const d = p.ray_d[pid];
+                rp.origin = mk3(o.x, o.y, o.z);
+                rp.direction = mk3(d.x, d.y, d.z);
+                float4 const h0 = p.hit0[pid];
+                pr.best.instance = __float_as_uint(h0.x);
+                pr.hit = pr.best.instance != RT_HIP_MISS;
+                if (pr.hit) {
+                    float2 const h1 = p.hit1[pid];
+                    pr.best.triangle = __float_as_uint(h0.y);
+                    pr.best.b0 = h0.z;
+                    pr.best.b1 = h0.w;
+                    pr.best.b2 = h1.x;
+                    pr.best.t = h1.y;
+                }
+            }
+            shade_trip(p.sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
+            p.rad[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
+                __uint_as_float(ps.depth));
+            if (rp.has_closest || rp.has_shadow) {
+                p.thr[pid] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z,
+                    __uint_as_float(ps.seed));
+                p.nee[pid] = make_float4(ps.nee.x, ps.nee.y, ps.nee.z, ps.last_bsdf_pdf);
+            }
+            if (rp.has_closest) {
+                p.ray_o[pid] = make_float4(rp.origin.x, rp.origin.y, rp.origin.z, 0.0f);
+                p.ray_d[pid] = make_float4(rp.direction.x, rp.direction.y, rp.direction.z, 0.0f);
+            }
+            if (rp.has_shadow) {
+                p.sh_o[pid] = make_float4(rp.shadow_origin.x, rp.shadow_origin.y,
+                    rp.shadow_origin.z, rp.shadow_t_max);
+                p.sh_d[pid] = make_float4(rp.shadow_direction.x, rp.shadow_direction.y,
+                    rp.shadow_direction.z, 0.0f);
+            }
+        } else {
+            rp.has_shadow = false;
+            rp.has_closest = false;
+        }
+        bool const goes_on = rp.has_closest || rp.has_shadow;
+        publish_raw(p, chunk, i, active,
+            goes_on ? (pid | (rp.has_closest ? kLiveHasClosest : 0u) |
+                          (rp.has_shadow ? kLiveHasShadow : 0u))
+                    : 0u);
+        total_hits += closest_hits;
+        total_skipped += shadow_skipped;
+    }
+    unsigned long long const hits = wave_sum(total_hits);
+    unsigned long long const skipped = wave_sum(total_skipped);
+    if (wave_lane() == 0) {
+        add_wave_stat(p, kStatClosestHits, hits);
+        add_wave_stat(p, kStatShadowSkipped, skipped);
+    }
+}
+
+// Adds the batch's finished paths to the frame, pass by pass
+// (megakernel_raytracer.comp:108-113 once per pass, in pass order).
+__global__ void __launch_bounds__(256) wf_resolve_kernel(wavefront_params const p) {
+    uint32_t const in_pass = blockIdx.x * 256u + threadIdx.x;
+    uint32_t x, y, pass;
+    if (in_pass >= p.block_count * 64u || !pid_pixel(p, in_pass, x, y, pass)) {
+        return;
+    }
+    float* const px = p.accum + 4u * ((size_t) y * p.frame_width + x);
+    f3 acc = splat3(0.0f);
+    if (!p.preview) {
+        float4 const old = *reinterpret_cast<const float4*>(px);
+        acc = mk3(old.x, old.y, old.z);
+    }
+    uint32_t const per_pass = p.block_count * 64u;
+    for (uint32_t k = 0; k < p.pass_count; ++k) {
+        float4 const r = p.rad[(size_t) k * per_pass + in_pass];
+        f3 const radiance = mk3(r.x, r.y, r.z);
+        acc = p.preview ? radiance : acc + radiance;
+    }
+    *reinterpret_cast<float4*>(px) = make_float4(acc.x, acc.y, acc.z, 1.0f);
+}
+
+}  // namespace rtd

@@ -17,6 +17,9 @@ _lib = None
 ACCEL_REFERENCE = 0
 ACCEL_REBUILT = 1
 FLAG_COUNT_NODES = 1
+FLAG_FUSED = 2
+FLAG_TIME_KERNELS = 4
+KERNEL_RENDER, KERNEL_EXTEND, KERNEL_SHADE = 0, 1, 2
 MISS = 0xFFFFFFFF
 
 EXPORTS = [
@@ -24,7 +27,7 @@ EXPORTS = [
     "rt_hip_render", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes",
-    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_destroy", "rt_hip_last_error",
+    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
 
@@ -72,6 +75,7 @@ def lib():
         l.rt_hip_set_passes.argtypes = [C.c_void_p, C.c_uint32]
         l.rt_hip_stats.argtypes = [C.c_void_p, C.POINTER(T.Stats), C.c_int]
         l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
+        l.rt_hip_kernel_time_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), u32p]
         l.rt_hip_destroy.argtypes = [C.c_void_p]
         _lib = l
     return _lib
@@ -156,10 +160,10 @@ class HipRenderer:
         _check(lib().rt_hip_stats(self._h, C.byref(s), 1 if reset else 0))
         return s.as_dict()
 
-    def kernel_time(self):
+    def kernel_time(self, kernel=KERNEL_RENDER):
         ms = C.c_double()
         n = C.c_uint32()
-        _check(lib().rt_hip_kernel_time(self._h, C.byref(ms), C.byref(n)))
+        _check(lib().rt_hip_kernel_time_of(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
 
     def close(self):

@@ -29,11 +29,13 @@ def main():
     o_inst, o_tri, o_t, o_b = oracle.primary_ids(sc.desc, cam, W, H, tile, seeds[:1])
     o_acc, o_st = oracle.render(sc.desc, cam, W, H, md, tile, seeds)
     print(f"oracle: {time.time() - t0:.2f}s", o_st)
-    for accel in (hip.ACCEL_REFERENCE, hip.ACCEL_REBUILT):
-        r = hip.HipRenderer(W, H, md, tile, accel=accel, flags=hip.FLAG_COUNT_NODES)
+    fused_image = {}
+    for accel, extra in ((hip.ACCEL_REFERENCE, hip.FLAG_FUSED), (hip.ACCEL_REBUILT, hip.FLAG_FUSED),
+                         (hip.ACCEL_REFERENCE, 0), (hip.ACCEL_REBUILT, 0)):
+        r = hip.HipRenderer(W, H, md, tile, accel=accel, flags=hip.FLAG_COUNT_NODES | extra)
         t0 = time.time()
         r.upload_scene(sc.desc)
-        print(f"accel {accel}: upload {time.time() - t0:.3f}s")
+        print(f"accel {accel} {'fused' if extra else 'wavefront'}: upload {time.time() - t0:.3f}s")
         r.upload_seeds(seeds)
         g_inst, g_tri, g_t, g_b = r.primary_ids(cam, 0)
         bad = (g_inst != o_inst) | (g_tri != o_tri)
@@ -52,6 +54,11 @@ def main():
         print(f"  image: max abs {diff.max():.4g} mean abs {diff.mean():.4g} "
               f"frac(rel>1e-3) {(rel > 1e-3).mean():.5f} frac(exact) "
               f"{(g_acc == o_acc).mean():.5f} nan {np.isnan(g_acc).sum()}")
+        if extra:
+            fused_image[accel] = g_acc
+        else:
+            same = np.array_equal(g_acc.view(np.uint32), fused_image[accel].view(np.uint32))
+            print(f"  wavefront image bit-identical to fused: {same}")
         r.close()
 
 
