@@ -182,7 +182,9 @@ def main():
                 shade_ms, shade_n = r.kernel_time(hip.KERNEL_SHADE)
                 name = "wf_extend_kernel"
                 bytes_l = trace_bytes / max(n, 1)
-                extra = {"render_call_avg_ms": kernel_ms, "render_calls": launches,
+                extra = {"rays_per_bounce": [sum(r.trip_counts(t)[1:])
+                                             for t in range(args.max_depth + 1)],
+                         "render_call_avg_ms": kernel_ms, "render_calls": launches,
                          "shade_kernel_avg_ms": shade_ms, "shade_launches": shade_n,
                          "extend_ms_per_call": ms * n / launches,
                          "shade_ms_per_call": shade_ms * shade_n / launches}

@@ -152,6 +152,11 @@ int rt_hip_kernel_time(rt_hip_renderer* r, double* avg_ms, uint32_t* launches);
 int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
     uint32_t* launches);
 
+/* Diagnostics of the pipeline: in the most recent batch of passes, how many paths were
+ * alive in bounce `trip` (counts[0]) and how many closest-hit (counts[1]) and occlusion
+ * (counts[2]) rays it traced.  Synchronises the device.  No counterpart in the reference. */
+int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts);
+
 /* Replaces megakernel_raytracer_destroy (:793-813). */
 int rt_hip_destroy(rt_hip_renderer* r);
 

@@ -222,6 +222,138 @@ private:
     }
 };
 
+float child_area(wide_node const& n, int child) {
+    float const dx = child == 0 ? n.hi0x - n.lo0x : n.hi1x - n.lo1x;
+    float const dy = child == 0 ? n.hi0y - n.lo0y : n.hi1y - n.lo1y;
+    float const dz = child == 0 ? n.hi0z - n.lo0z : n.hi1z - n.lo1z;
+    return dx * dy + dy * dz + dz * dx;
+}
+
+float union_area(wide_node const& n) {
+    float const dx = std::max(n.hi0x, n.hi1x) - std::min(n.lo0x, n.lo1x);
+    float const dy = std::max(n.hi0y, n.hi1y) - std::min(n.lo0y, n.lo1y);
+    float const dz = std::max(n.hi0z, n.hi1z) - std::min(n.lo0z, n.lo1z);
+    return dx * dy + dy * dz + dz * dx;
+}
+
+// Renumbers nodes and instance records by how often a ray is expected to fetch them
+// (surface-area ratios down from the TLAS root, a BLAS shared by several instances adding
+// up), hottest first: the traversal kernel keeps a prefix of both arrays in LDS.
+void order_by_heat(built_accel& out) {
+    size_t const node_count = out.nodes.size();
+    std::vector<double> heat(node_count, 0.0);
+    std::vector<double> instance_heat(out.instances.size(), 0.0);
+    struct visit {
+        int32_t node;
+        double heat;
+    };
+    std::vector<visit> todo;
+    // Spreads `h` from `root` down one tree; `on_leaf(code, h)` sees the leaves.
+    auto spread = [&](int32_t root, double h, auto&& on_leaf) {
+        if (root < 0) {
+            on_leaf(root, h);
+            return;
+        }
+        todo.push_back({root, h});
+        while (!todo.empty()) {
+            visit const v = todo.back();
+            todo.pop_back();
+            heat[(size_t) v.node] += v.heat;
+            wide_node const& n = out.nodes[(size_t) v.node];
+            float const whole = union_area(n);
+            for (int child = 0; child < 2; ++child) {
+                double share = v.heat;
+                if (whole > 0.0f) {
+                    share = v.heat * std::min(1.0, (double) child_area(n, child) / (double) whole);
+                }
+                int32_t const c = child == 0 ? n.child0 : n.child1;
+                if (c >= 0) {
+                    todo.push_back({c, share});
+                } else {
+                    on_leaf(c, share);
+                }
+            }
+        }
+    };
+    spread(out.tlas_root, 1.0, [&](int32_t code, double h) {
+        instance_heat[((uint32_t) ~code) >> 3] += h;
+    });
+    std::vector<double> root_heat(node_count, 0.0);
+    for (size_t i = 0; i < out.instances.size(); ++i) {
+        if (out.instances[i].blas_root >= 0) {
+            root_heat[(size_t) out.instances[i].blas_root] += instance_heat[i];
+        }
+    }
+    for (size_t r = 0; r < node_count; ++r) {
+        if (root_heat[r] > 0.0) {
+            spread((int32_t) r, root_heat[r], [](int32_t, double) {});
+        }
+    }
+
+    auto ranking = [](std::vector<double> const& h) {
+        std::vector<uint32_t> order(h.size());
+        for (size_t i = 0; i < h.size(); ++i) {
+            order[i] = (uint32_t) i;
+        }
+        std::stable_sort(order.begin(), order.end(),
+            [&](uint32_t a, uint32_t b) { return h[a] > h[b]; });
+        std::vector<uint32_t> rank(h.size());
+        for (size_t i = 0; i < order.size(); ++i) {
+            rank[order[i]] = (uint32_t) i;
+        }
+        return rank;
+    };
+    std::vector<uint32_t> const node_rank = ranking(heat);
+    std::vector<uint32_t> const instance_rank = ranking(instance_heat);
+
+    // TLAS leaves name instance records; find them before the nodes move.
+    std::vector<char> is_tlas(node_count, 0);
+    {
+        std::vector<int32_t> walk;
+        if (out.tlas_root >= 0) {
+            walk.push_back(out.tlas_root);
+        }
+        while (!walk.empty()) {
+            int32_t const v = walk.back();
+            walk.pop_back();
+            is_tlas[(size_t) v] = 1;
+            if (out.nodes[(size_t) v].child0 >= 0) {
+                walk.push_back(out.nodes[(size_t) v].child0);
+            }
+            if (out.nodes[(size_t) v].child1 >= 0) {
+                walk.push_back(out.nodes[(size_t) v].child1);
+            }
+        }
+    }
+    auto remap = [&](int32_t ref, bool tlas) -> int32_t {
+        if (ref >= 0) {
+            return (int32_t) node_rank[(size_t) ref];
+        }
+        if (tlas) {
+            return encode_leaf(instance_rank[((uint32_t) ~ref) >> 3], 1u);
+        }
+        return ref;  // triangle ranges stay where they are
+    };
+    std::vector<wide_node> nodes(node_count);
+    for (size_t i = 0; i < node_count; ++i) {
+        wide_node n = out.nodes[i];
+        n.child0 = remap(n.child0, is_tlas[i] != 0);
+        n.child1 = remap(n.child1, is_tlas[i] != 0);
+        nodes[node_rank[i]] = n;
+    }
+    out.nodes.swap(nodes);
+    out.tlas_root = remap(out.tlas_root, true);
+    std::vector<instance_rec> instances(out.instances.size());
+    for (size_t i = 0; i < out.instances.size(); ++i) {
+        instance_rec rec = out.instances[i];
+        if (rec.blas_root >= 0) {
+            rec.blas_root = (int32_t) node_rank[(size_t) rec.blas_root];
+        }
+        instances[instance_rank[i]] = rec;
+    }
+    out.instances.swap(instances);
+}
+
 void set_centroid(build_prim& p) {
     for (int a = 0; a < 3; ++a) {
         p.centroid[a] = 0.5f * (p.bounds.lo[a] + p.bounds.hi[a]);
@@ -370,6 +502,7 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
         rec.blas_root = mesh_root[(uint32_t) rec.blas_root];
     }
     out.max_stack_bound = deepest_tlas + 1u + deepest_blas;
+    order_by_heat(out);
     return out;
 }
 

@@ -11,9 +11,9 @@
 namespace rtd {
 
 struct built_accel {
-    std::vector<wide_node> nodes;         // every BLAS, then the TLAS
+    std::vector<wide_node> nodes;         // TLAS and every BLAS, most visited first
     std::vector<tri_pos> tris;            // leaf order; ref_index -> uploaded triangles[]
-    std::vector<instance_rec> instances;  // TLAS leaf order
+    std::vector<instance_rec> instances;  // most visited first
     int32_t tlas_root = 0;                // node index, or an encoded leaf
     uint32_t max_stack_bound = 0;         // TLAS depth + 1 + deepest BLAS depth
 };

@@ -70,7 +70,56 @@ struct scene_dev {
     int32_t wide_tlas_root;
     uint32_t light_count;
     int32_t sky_light;
-    uint32_t _pad;
+    // LDS plan of the cached traversal kernel: per-lane stack entries, and how many of the
+    // first nodes / instance records each workgroup copies into LDS
+    uint32_t stack_entries;
+    uint32_t cached_nodes;
+    uint32_t cached_instances;
+    // sizes of the small tables the shading kernel may stage in LDS
+    uint32_t instance_count, transform_count, material_count, mesh_count, texture_count;
 };
+
+// Which of the scene's small tables the shading kernel copies into LDS, and where.  The
+// tables are read with per-lane indices (the hit instance, its material, a random light):
+// from LDS such a read costs a few cycles, from memory one cache-line lookup per lane.
+enum : uint32_t {
+    kTableLights = 0,
+    kTableMaterials,
+    kTableMeshes,
+    kTableTextures,
+    kTableInstances,
+    kTableTransforms,
+    kTableCount,
+};
+constexpr uint32_t kNotStaged = 0xFFFFFFFFu;
+
+struct shade_plan {
+    uint32_t offset[kTableCount];  // byte offset in LDS, or kNotStaged
+    uint32_t bytes[kTableCount];
+    uint32_t total;
+};
+
+// Greedy in the order of the enum (smallest and most used first); host and kernel run the
+// same function, so they agree on the layout without passing it around.
+__host__ __device__ inline shade_plan plan_shade_tables(scene_dev const& sc, uint32_t budget) {
+    shade_plan plan;
+    plan.bytes[kTableLights] = sc.light_count * (uint32_t) sizeof(rt_light);
+    plan.bytes[kTableMaterials] = sc.material_count * (uint32_t) sizeof(rt_material);
+    plan.bytes[kTableMeshes] = sc.mesh_count * (uint32_t) sizeof(rt_mesh);
+    plan.bytes[kTableTextures] = sc.texture_count * (uint32_t) sizeof(texture_dev);
+    plan.bytes[kTableInstances] = sc.instance_count * (uint32_t) sizeof(rt_instance);
+    plan.bytes[kTableTransforms] = sc.transform_count * (uint32_t) sizeof(rt_mat4);
+    plan.total = 0;
+    for (uint32_t t = 0; t < kTableCount; ++t) {
+        uint32_t const padded = (plan.bytes[t] + 15u) & ~15u;
+        if (plan.bytes[t] != 0u && plan.total + padded <= budget) {
+            plan.offset[t] = plan.total;
+            plan.total += padded;
+        } else {
+            plan.offset[t] = kNotStaged;
+        }
+    }
+    return plan;
+}
 
 }  // namespace rtd

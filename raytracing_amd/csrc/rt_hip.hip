@@ -351,7 +351,8 @@ struct rt_hip_renderer {
     wavefront_params wf{};
     size_t wf_paths = 0;
     uint32_t wf_trips = 0;
-    uint32_t wf_extend_grid = 0, wf_shade_grid = 0;
+    uint32_t wf_extend_grid = 0, wf_extend_waves = 0, wf_shade_grid = 0;  // workgroups, waves
+    uint32_t wf_finish_grid = 0;
 
     struct timed_launch {
         hipEvent_t start, stop;
@@ -568,6 +569,9 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
     }
 }
 
+// Bounce from which the pipeline hands the surviving paths to wf_finish_kernel.
+constexpr uint32_t kWavefrontFinishTrip = 4;
+
 // Paths in flight per batch of the wavefront pipeline: 2^25 paths = 4.6 GB of state.
 constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 25;
 
@@ -583,15 +587,28 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips) {
         };
         bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
         if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
-            r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true>)
-                                     : resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false>);
+            r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true, false>)
+                                     : resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false, false>);
+            r.wf_extend_waves = r.wf_extend_grid;
         } else {
-            r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true>)
-                                     : resident(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false>);
+            // one workgroup per CU: it takes (nearly) all of the CU's LDS
+            r.wf_extend_grid = cus;
+            r.wf_extend_waves = cus * (kExtendThreads / 64u);
+            auto allow = [&](auto kernel) {
+                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) kLdsBytesPerCu));
+            };
+            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, false>);
+            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, false>);
+            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, true>);
+            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, true>);
         }
-        r.wf_shade_grid = resident(wf_shade_kernel);
+        // two workgroups of four waves per CU (the kernel's registers allow two waves per
+        // SIMD), each with its own LDS copy of the scene's small tables
+        r.wf_shade_grid = cus * 2u;
+        r.wf_finish_grid = cus * 8u;  // one-wave workgroups, two per SIMD
         // per-wave work counters: allocated once, they outlive a regrowth of the state arrays
-        size_t const stat_bytes = (size_t) std::max(r.wf_extend_grid, r.wf_shade_grid) *
+        size_t const stat_bytes = (size_t) std::max({r.wf_extend_waves, r.wf_shade_grid * (kShadeThreads / 64u), r.wf_finish_grid}) *
                                   kStatWords * sizeof(unsigned long long);
         HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
         HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
@@ -668,21 +685,62 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
     bool const each = (r.cfg.flags & RT_HIP_FLAG_TIME_KERNELS) != 0;
 
-    auto extend = [&](uint32_t trip, dim3 grid) {
+    uint32_t const extend_lds =
+        (w.sc.cached_nodes + w.sc.cached_instances) * 64u +
+        (kExtendThreads / 64u) * w.sc.stack_entries * 256u;
+    uint32_t const shade_lds = plan_shade_tables(w.sc, kShadeLdsBudget).total;
+    auto extend = [&](uint32_t trip, uint32_t chunk_bound) {
+        bool const reference = r.cfg.accel == RT_HIP_ACCEL_REFERENCE;
+        uint32_t const per_group = reference ? 1u : kExtendThreads / 64u;
+        dim3 const grid(std::min(r.wf_extend_grid, (chunk_bound + per_group - 1u) / per_group));
+        dim3 const block(reference ? 64u : kExtendThreads);
+        uint32_t const lds = reference ? 0u : extend_lds;
+        auto go = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, grid, block, lds, stream, w, trip);
+        };
+        bool const first = trip == 0u;
+        if (reference) {
+            if (count) {
+                first ? go(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true, true>)
+                      : go(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true, false>);
+            } else {
+                first ? go(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false, true>)
+                      : go(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false, false>);
+            }
+        } else {
+            if (count) {
+                first ? go(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, true>)
+                      : go(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, false>);
+            } else {
+                first ? go(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, true>)
+                      : go(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, false>);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+    };
+    // From this trip on the surviving paths are finished by one fused launch.
+    static uint32_t const finish_trip_setting = [] {
+        char const* v = getenv("RT_HIP_FINISH_TRIP");  // tuning knob
+        return v ? (uint32_t) std::max(0, atoi(v)) : kWavefrontFinishTrip;
+    }();
+    // trip 0 always runs as launches (the finishing kernel starts from stored path state)
+    uint32_t const finish_trip = std::max(1u, finish_trip_setting);
+    auto finish = [&](uint32_t trip, uint32_t chunk_bound) {
+        dim3 const grid(std::max(1u, std::min(r.wf_finish_grid, chunk_bound)));
         if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
             if (count) {
-                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true>), grid, dim3(64),
+                hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REFERENCE, true>), grid, dim3(64),
                     0, stream, w, trip);
             } else {
-                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false>), grid,
+                hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REFERENCE, false>), grid,
                     dim3(64), 0, stream, w, trip);
             }
         } else {
             if (count) {
-                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true>), grid, dim3(64),
+                hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REBUILT, true>), grid, dim3(64),
                     0, stream, w, trip);
             } else {
-                hipLaunchKernelGGL((wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false>), grid, dim3(64),
+                hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REBUILT, false>), grid, dim3(64),
                     0, stream, w, trip);
             }
         }
@@ -690,13 +748,13 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     };
     // Builds trip `trip`'s lists from the raw slots its producer left behind.
     auto compact = [&](uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count,
-                       uint32_t chunk_bound) {
+                       uint32_t chunk_bound, bool count_rays) {
         dim3 const tiles(std::max(1u, (chunk_bound + kTileChunks - 1u) / kTileChunks));
         hipLaunchKernelGGL(wf_tile_sums_kernel, tiles, dim3(kTileThreads), 0, stream, w,
             in_count_ptr, in_count);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(wf_scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, stream, w, trip,
-            in_count_ptr, in_count);
+            in_count_ptr, in_count, count_rays ? 1u : 0u);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(wf_scatter_kernel, tiles, dim3(kTileThreads), 0, stream, w,
             in_count_ptr, in_count);
@@ -709,31 +767,40 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         w.seeds = p.seeds ? p.seeds + (size_t) first * p.tile_count : nullptr;
         size_t const paths = per_pass * w.pass_count;
         uint32_t const chunk_bound = (uint32_t) (paths / 64u);
-        hipLaunchKernelGGL(wf_generate_kernel, dim3((uint32_t) ((paths + 255u) / 256u)), dim3(256),
-            0, stream, w);
-        HIP_CHECK(hipGetLastError());
-        compact(0, nullptr, (uint32_t) paths, chunk_bound);
+        HIP_CHECK(hipMemsetAsync(w.control, 0, (size_t) (trips + 1u) * kCtlWords * 4, stream));
         for (uint32_t trip = 0; trip < trips; ++trip) {
+            if (trip == finish_trip) {
+                finish(trip, chunk_bound);
+                break;
+            }
             // a trip has at most one closest-hit and one occlusion ray per path
-            dim3 const extend_grid(std::min(r.wf_extend_grid, 2u * chunk_bound));
-            dim3 const shade_grid(std::min(r.wf_shade_grid, chunk_bound));
+            dim3 const shade_grid(std::min(r.wf_shade_grid,
+                (chunk_bound + kShadeThreads / 64u - 1u) / (kShadeThreads / 64u)));
             rt_hip_renderer::timed_launch t{};
             if (each) {
                 t = r.begin_timing(stream, RT_HIP_KERNEL_EXTEND);
             }
-            extend(trip, extend_grid);
+            extend(trip, trip == 0u ? chunk_bound : 2u * chunk_bound);
             if (each) {
                 r.end_timing(t, stream);
                 t = r.begin_timing(stream, RT_HIP_KERNEL_SHADE);
             }
-            hipLaunchKernelGGL(wf_shade_kernel, shade_grid, dim3(64), 0, stream, w, trip);
+            if (trip == 0u) {
+                hipLaunchKernelGGL(wf_shade_kernel<true>, shade_grid, dim3(kShadeThreads),
+                    shade_lds, stream, w, trip);
+            } else {
+                hipLaunchKernelGGL(wf_shade_kernel<false>, shade_grid, dim3(kShadeThreads),
+                    shade_lds, stream, w, trip);
+            }
             HIP_CHECK(hipGetLastError());
             if (each) {
                 r.end_timing(t, stream);
             }
             if (trip + 1u < trips) {
                 // nothing survives the last trip: its paths are at max_depth
-                compact(trip + 1u, w.control + trip * kCtlWords + kCtlLive, 0u, chunk_bound);
+                // trip 0 publishes one raw slot per path, later trips one per live path
+                compact(trip + 1u, trip == 0u ? nullptr : w.control + trip * kCtlWords + kCtlLive,
+                    (uint32_t) paths, chunk_bound, trip + 1u != finish_trip);
             }
         }
         hipLaunchKernelGGL(wf_resolve_kernel, dim3((uint32_t) ((per_pass + 255u) / 256u)),
@@ -866,6 +933,11 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         d.textures = r->upload(textures.data(), textures.size());
         d.light_count = s.light_count;
         d.sky_light = s.sky_light;
+        d.instance_count = s.instance_count;
+        d.transform_count = s.transform_count;
+        d.material_count = s.material_count;
+        d.mesh_count = s.mesh_count;
+        d.texture_count = s.texture_count;
         if (r->cfg.accel == RT_HIP_ACCEL_REFERENCE) {
             uint32_t blas_depth = 0;
             for (uint32_t m = 0; m < s.mesh_count; ++m) {
@@ -887,6 +959,15 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             d.wide_tris = r->upload(accel.tris.data(), accel.tris.size());
             d.wide_instances = r->upload(accel.instances.data(), accel.instances.size());
             d.wide_tlas_root = accel.tlas_root;
+            // LDS plan of the cached traversal kernel (wf_extend_kernel): stacks first, the
+            // rest goes to the instance records (at most half) and the hottest nodes.
+            d.stack_entries = std::max(1u, accel.max_stack_bound);
+            uint32_t const stack_bytes = (kExtendThreads / 64u) * d.stack_entries * 256u;
+            uint32_t const spare = kLdsBytesPerCu - stack_bytes;
+            d.cached_instances =
+                (uint32_t) std::min<size_t>(accel.instances.size(), spare / 2u / 64u);
+            d.cached_nodes = (uint32_t) std::min<size_t>(accel.nodes.size(),
+                (spare - d.cached_instances * 64u) / 64u);
         }
         r->sc = d;
         r->scene_ready = true;
@@ -1151,12 +1232,17 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
         HIP_CHECK(hipMemcpy(words, r->counters, sizeof(words), hipMemcpyDeviceToHost));
         if (r->wf.wave_stats != nullptr) {
             // the pipeline keeps its work counters per wave
-            size_t const waves = std::max(r->wf_extend_grid, r->wf_shade_grid);
+            size_t const waves =
+                std::max({r->wf_extend_waves, r->wf_shade_grid * (kShadeThreads / 64u),
+                    r->wf_finish_grid});
             std::vector<unsigned long long> per_wave(waves * kStatWords);
             HIP_CHECK(hipMemcpy(per_wave.data(), r->wf.wave_stats,
                 per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
             for (size_t wv = 0; wv < waves; ++wv) {
                 unsigned long long const* s = &per_wave[wv * kStatWords];
+                words[0] += s[kStatSamples];
+                words[1] += s[kStatSamples] + s[kStatClosestRays];
+                words[2] += s[kStatShadowRays];
                 words[3] += s[kStatClosestHits];
                 words[7] += s[kStatShadowSkipped];
                 words[4] += s[kStatNodes];
@@ -1214,6 +1300,25 @@ int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
         if (launches) {
             *launches = r->launches_total[kernel];
         }
+    });
+}
+
+int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts) {
+    return guarded([&] {
+        if (!r || !counts) {
+            throw std::runtime_error("trip_counts: null argument");
+        }
+        if (r->wf_allocs.empty() || trip >= r->wf_trips) {
+            throw std::runtime_error("trip_counts: no pipeline batch has run that many trips");
+        }
+        r->use_device();
+        HIP_CHECK(hipDeviceSynchronize());
+        uint32_t words[kCtlWords];
+        HIP_CHECK(hipMemcpy(words, r->wf.control + (size_t) trip * kCtlWords, sizeof(words),
+            hipMemcpyDeviceToHost));
+        counts[0] = words[kCtlLive];
+        counts[1] = words[kCtlClosest];
+        counts[2] = words[kCtlShadow];
     });
 }
 

@@ -39,6 +39,11 @@ constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
 
 struct fast_stack {
     uint32_t* lds;  // this lane's column: entry e at lds[e * 64]
+    // LDS copies of the first (most visited) nodes and instance records, CACHED walks only
+    const float4* node_cache;
+    const float4* instance_cache;
+    uint32_t cached_nodes;
+    uint32_t cached_instances;
 };
 
 struct slab_ray {
@@ -88,12 +93,20 @@ struct pair_result {
 // ANY = false: closest hit (best is filled, returns whether anything was hit).
 // ANY = true : occlusion query over (0, t_limit]; returns on the first hit.
 // Lanes with active == false skip the walk (their ray does not exist).
-template <bool ANY, bool COUNT>
+// CACHED: nodes / instance records below stk.cached_* are read from LDS, where a fetch
+// that differs per lane costs a few cycles instead of one cache-line lookup per lane in the
+// vector memory pipeline (which is what bounds this walk), and the stack holds as many
+// entries as the scene needs instead of kFastLdsEntries.
+template <bool ANY, bool COUNT, bool CACHED = false>
 RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, f3 origin,
     f3 direction, float t_limit, hit_result& best, trace_counters& cnt) {
     uint32_t sp = 0;
+    auto slot = [&](uint32_t entry) -> uint32_t {
+        // never wraps: the builder bounds the depth and upload checks it against the stack
+        return (CACHED ? entry : (entry & (kFastLdsEntries - 1u))) * 64u;
+    };
     auto push = [&](int32_t v) {
-        stk.lds[(sp & (kFastLdsEntries - 1u)) * 64u] = (uint32_t) v;  // never wraps, see above
+        stk.lds[slot(sp)] = (uint32_t) v;
         ++sp;
         if (COUNT) {
             cnt.max_stack = max(cnt.max_stack, sp);
@@ -101,7 +114,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     };
     auto pop = [&]() -> int32_t {
         --sp;
-        return (int32_t) stk.lds[(sp & (kFastLdsEntries - 1u)) * 64u];
+        return (int32_t) stk.lds[slot(sp)];
     };
 
     float t_max = t_limit;
@@ -120,7 +133,13 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     for (;;) {
         if (cur >= 0) {
             const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
-            float4 const n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            float4 n0, n1, n2, n3;
+            if (CACHED && (uint32_t) cur < stk.cached_nodes) {
+                const float4* lp = stk.node_cache + 4u * (uint32_t) cur;
+                n0 = lp[0], n1 = lp[1], n2 = lp[2], n3 = lp[3];
+            } else {
+                n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+            }
             if (COUNT) {
                 ++cnt.nodes;
             }
@@ -145,7 +164,13 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             // TLAS leaf: exactly one instance.  Enter its BLAS.
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
             const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
-            float4 const r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
+            float4 r0, r1, r2, r3;
+            if (CACHED && rec_index < stk.cached_instances) {
+                const float4* lp = stk.instance_cache + 4u * rec_index;
+                r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+            } else {
+                r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
+            }
             // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
             f3 o, d;
             o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;

@@ -44,6 +44,9 @@ enum : uint32_t {
 
 // Per-wave work counters (wave_stats[slot][k]); slot = wave index in its launch.
 enum : uint32_t {
+    kStatSamples = 7,      // paths started (trip 0 has no list whose length could be read)
+    kStatClosestRays = 0,  // rays traced by the finishing kernel only (the per-trip launches
+    kStatShadowRays = 6,   // take their ray counts from the list lengths)
     kStatClosestHits = 1,
     kStatShadowSkipped = 2,
     kStatNodes = 3,
@@ -143,38 +146,33 @@ RT_DEV bool pid_pixel(wavefront_params const& p, uint32_t pid, uint32_t& x, uint
     return x < p.x1 && y < p.y1;
 }
 
-// Starts every path of the batch: seeds it, builds its primary ray
-// (megakernel_raytracer.comp:85-100) and publishes it as raw slot `pid`.
-__global__ void __launch_bounds__(256) wf_generate_kernel(wavefront_params const p) {
-    uint32_t const pid = blockIdx.x * 256u + threadIdx.x;
-    uint32_t const paths = p.pass_count * p.block_count * 64u;  // a multiple of 64
+// Start of path `pid`: its pixel, its seed after the two jitter draws and its primary ray
+// (megakernel_raytracer.comp:85-100).  Trip 0 has no stored state: the trace launch and the
+// shade launch both derive the primary ray from the pid (same arithmetic, same bits), which
+// is cheaper than writing it to memory and reading it back twice.
+RT_DEV bool primary_of_pid(wavefront_params const& p, uint32_t pid, uint32_t& seed, f3& origin,
+    f3& direction) {
     uint32_t x, y, pass;
-    bool const valid = pid < paths && pid_pixel(p, pid, x, y, pass);
-    if (valid) {
-        uint32_t random_seed = p.scalar_seed;
-        if (p.seeds != nullptr) {
-            uint32_t const tile = (y / p.tile_height) * p.tiles_x + x / p.tile_width;
-            random_seed = p.seeds[(size_t) pass * p.tile_count + tile];
-        }
-        f3 const du = load3(p.cam.pixel_delta_u);
-        f3 const dv = load3(p.cam.pixel_delta_v);
-        f3 const ul = load3(p.cam.upper_left_pixel);
-        f3 const pos = load3(p.cam.position);
-        uint32_t seed = hash_combine(random_seed, p.frame_width * y + x);
-        f3 const pixel = (ul + du * (float) (int) x) + dv * (float) (int) y;
-        float const ox = -0.5f + rand_01(seed);
-        float const oy = -0.5f + rand_01(seed);
-        f3 const pixel_sample = pixel + (du * ox + dv * oy);
-        f3 const direction = normalize3(pixel_sample - pos);
-        p.ray_o[pid] = make_float4(pos.x, pos.y, pos.z, 0.0f);
-        p.ray_d[pid] = make_float4(direction.x, direction.y, direction.z, 0.0f);
-        p.nee[pid] = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        p.thr[pid] = make_float4(1.0f, 1.0f, 1.0f, __uint_as_float(seed));
-        p.rad[pid] = make_float4(0.0f, 0.0f, 0.0f, __uint_as_float(0u));
+    if (pid >= p.pass_count * p.block_count * 64u || !pid_pixel(p, pid, x, y, pass)) {
+        return false;
     }
-    if (pid < paths) {  // whole waves: paths is a multiple of 64
-        publish_raw(p, pid >> 6, pid, true, valid ? (pid | kLiveHasClosest) : 0u);
+    uint32_t random_seed = p.scalar_seed;
+    if (p.seeds != nullptr) {
+        uint32_t const tile = (y / p.tile_height) * p.tiles_x + x / p.tile_width;
+        random_seed = p.seeds[(size_t) pass * p.tile_count + tile];
     }
+    f3 const du = load3(p.cam.pixel_delta_u);
+    f3 const dv = load3(p.cam.pixel_delta_v);
+    f3 const ul = load3(p.cam.upper_left_pixel);
+    f3 const pos = load3(p.cam.position);
+    seed = hash_combine(random_seed, p.frame_width * y + x);
+    f3 const pixel = (ul + du * (float) (int) x) + dv * (float) (int) y;
+    float const ox = -0.5f + rand_01(seed);
+    float const oy = -0.5f + rand_01(seed);
+    f3 const pixel_sample = pixel + (du * ox + dv * oy);
+    origin = pos;
+    direction = normalize3(pixel_sample - pos);
+    return true;
 }
 
 // Compaction of the raw slots into trip `trip`'s lists, in three small launches over tiles of
@@ -239,8 +237,10 @@ __global__ void __launch_bounds__(kTileThreads) wf_tile_sums_kernel(wavefront_pa
     }
 }
 
+// count_rays: the trip's rays are traced by per-trip launches (not by the finishing kernel,
+// which counts its own).
 __global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_params const p,
-    uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count) {
+    uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count, uint32_t count_rays) {
     __shared__ uint32_t scratch[3][kScanThreads];
     uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
     uint32_t const chunks = (n + 63u) / 64u;
@@ -262,11 +262,10 @@ __global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_p
         ctl[kCtlClosest] = incl.closest;
         ctl[kCtlShadow] = incl.shadow;
         // single thread of a single workgroup, launches of one renderer are stream-ordered
-        if (trip == 0u) {
-            p.counters[0] += incl.live;  // every path of the batch starts in trip 0
+        if (count_rays != 0u) {
+            p.counters[1] += incl.closest;
+            p.counters[2] += incl.shadow;
         }
-        p.counters[1] += incl.closest;
-        p.counters[2] += incl.shadow;
     }
 }
 
@@ -331,28 +330,76 @@ __global__ void __launch_bounds__(kTileThreads) wf_scatter_kernel(wavefront_para
 }
 
 // Traces every ray of trip `trip`: chunks [0, closest_chunks) hold closest-hit rays, the
-// rest occlusion rays, so a wave never mixes the two kinds.
-template <int ACCEL, bool COUNT>
-__global__ void __launch_bounds__(64, ACCEL == RT_HIP_ACCEL_REBUILT ? 5 : 2)
+// rest occlusion rays, so a wave never mixes the two kinds.  (A variant in which a lane that
+// finishes its ray takes the next one from the queue, instead of waiting for the slowest
+// ray of its chunk, measured no faster on incoherent rays and 1.8x slower on primary rays:
+// the refills expose the latency of the ray loads and repeat the per-ray set-up at partial
+// occupancy.)
+//
+// Rebuilt acceleration structure: workgroups of kExtendThreads threads; LDS holds, in this
+// order, the hottest nodes, the hottest instance records (both copied in by the workgroup
+// before it starts) and every wave's traversal stack.  Reference-order structure: one wave
+// per workgroup, private stack, no LDS.
+constexpr uint32_t kExtendThreads = 1024;
+constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
+
+// FIRST: trip 0 - the rays are the primary rays of pids 0 .. paths-1, built on the spot.
+template <int ACCEL, bool COUNT, bool FIRST>
+__global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads : 64)
     wf_extend_kernel(wavefront_params const p, uint32_t trip) {
-    __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
-    fast_stack stk;
-    stk.lds = lds_stack + threadIdx.x;
+    extern __shared__ float4 extend_lds[];
     const uint32_t* const ctl = p.control + trip * kCtlWords;
-    uint32_t const n_closest = ctl[kCtlClosest];
-    uint32_t const n_shadow = ctl[kCtlShadow];
+    uint32_t const n_closest = FIRST ? p.pass_count * p.block_count * 64u : ctl[kCtlClosest];
+    uint32_t const n_shadow = FIRST ? 0u : ctl[kCtlShadow];
     uint32_t const closest_chunks = (n_closest + 63u) / 64u;
     uint32_t const total_chunks = closest_chunks + (n_shadow + 63u) / 64u;
     const uint32_t* const q_closest = p.q_closest;
     const uint32_t* const q_shadow = p.q_shadow;
+    fast_stack stk{};
+    if (ACCEL == RT_HIP_ACCEL_REBUILT) {
+        if (blockIdx.x * (kExtendThreads / 64u) >= total_chunks) {
+            return;  // none of this workgroup's waves has a chunk: skip filling the caches
+        }
+        uint32_t const node_words = p.sc.cached_nodes * 4u;
+        uint32_t const instance_words = p.sc.cached_instances * 4u;
+        const float4* const nodes = reinterpret_cast<const float4*>(p.sc.wide_nodes);
+        const float4* const records = reinterpret_cast<const float4*>(p.sc.wide_instances);
+        for (uint32_t i = threadIdx.x; i < node_words; i += kExtendThreads) {
+            extend_lds[i] = nodes[i];
+        }
+        for (uint32_t i = threadIdx.x; i < instance_words; i += kExtendThreads) {
+            extend_lds[node_words + i] = records[i];
+        }
+        __syncthreads();
+        stk.node_cache = extend_lds;
+        stk.instance_cache = extend_lds + node_words;
+        stk.cached_nodes = p.sc.cached_nodes;
+        stk.cached_instances = p.sc.cached_instances;
+        stk.lds = reinterpret_cast<uint32_t*>(extend_lds + node_words + instance_words) +
+                  (threadIdx.x >> 6) * p.sc.stack_entries * 64u + wave_lane();
+    }
     trace_counters cnt;
+    if (FIRST && blockIdx.x == 0 && threadIdx.x == 0) {
+        // for rt_hip_trip_counts; includes the unused lanes of partial 8x8 blocks
+        uint32_t* const first_ctl = p.control;
+        first_ctl[kCtlLive] = n_closest;
+        first_ctl[kCtlClosest] = n_closest;
+    }
     for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
         if (chunk < closest_chunks) {
             uint32_t const i = chunk * 64u + wave_lane();
-            bool const active = i < n_closest;
-            uint32_t const pid = active ? q_closest[i] : 0u;
+            bool active = i < n_closest;
+            uint32_t const pid = FIRST ? i : (active ? q_closest[i] : 0u);
             float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
-            if (active) {
+            if (FIRST) {
+                uint32_t seed;
+                f3 origin, direction;
+                active = primary_of_pid(p, pid, seed, origin, direction);
+                if (active) {
+                    o = make_float4(origin.x, origin.y, origin.z, 0.0f);
+                    d = make_float4(direction.x, direction.y, direction.z, 0.0f);
+                }
+            } else if (active) {
                 o = p.ray_o[pid];
                 d = p.ray_d[pid];
             }
@@ -363,7 +410,7 @@ __global__ void __launch_bounds__(64, ACCEL == RT_HIP_ACCEL_REBUILT ? 5 : 2)
             best.t = kInfinity;
             bool hit;
             if (ACCEL == RT_HIP_ACCEL_REBUILT) {
-                hit = trace_fast<false, COUNT>(p.sc, stk, active, mk3(o.x, o.y, o.z),
+                hit = trace_fast<false, COUNT, true>(p.sc, stk, active, mk3(o.x, o.y, o.z),
                     mk3(d.x, d.y, d.z), kInfinity, best, cnt);
             } else {
                 hit = active && trace_ref<false, COUNT>(p.sc, mk3(o.x, o.y, o.z),
@@ -386,7 +433,7 @@ __global__ void __launch_bounds__(64, ACCEL == RT_HIP_ACCEL_REBUILT ? 5 : 2)
             hit_result unused;
             bool blocked;
             if (ACCEL == RT_HIP_ACCEL_REBUILT) {
-                blocked = trace_fast<true, COUNT>(p.sc, stk, active, mk3(o.x, o.y, o.z),
+                blocked = trace_fast<true, COUNT, true>(p.sc, stk, active, mk3(o.x, o.y, o.z),
                     mk3(d.x, d.y, d.z), o.w, unused, cnt);
             } else {
                 blocked = active && trace_ref<true, COUNT>(p.sc, mk3(o.x, o.y, o.z),
@@ -416,39 +463,97 @@ __global__ void __launch_bounds__(64, ACCEL == RT_HIP_ACCEL_REBUILT ? 5 : 2)
 
 // Shades every live path of trip `trip`; survivors are published as raw slots for the
 // compaction that builds trip + 1's lists.
-__global__ void __launch_bounds__(64, 2) wf_shade_kernel(wavefront_params const p, uint32_t trip) {
-    uint32_t const n_live = p.control[trip * kCtlWords + kCtlLive];
+//
+// Workgroups of kShadeThreads threads; each first copies the scene's small tables into LDS
+// (plan_shade_tables) and points its copy of the scene description at them, so the shading
+// code reads them through the same pointers either way.
+constexpr uint32_t kShadeThreads = 256;
+constexpr uint32_t kShadeLdsBudget = 64u * 1024u;
+
+// FIRST: trip 0 - the live paths are pids 0 .. paths-1 with their initial state.
+template <bool FIRST>
+__global__ void __launch_bounds__(kShadeThreads, 2)
+    wf_shade_kernel(wavefront_params const p, uint32_t trip) {
+    extern __shared__ float4 shade_lds[];
+    uint32_t const n_live =
+        FIRST ? p.pass_count * p.block_count * 64u : p.control[trip * kCtlWords + kCtlLive];
     uint32_t const total_chunks = (n_live + 63u) / 64u;
+    if (blockIdx.x * (kShadeThreads / 64u) >= total_chunks) {
+        return;  // none of this workgroup's waves has a chunk
+    }
+    scene_dev sc = p.sc;
+    {
+        shade_plan const plan = plan_shade_tables(p.sc, kShadeLdsBudget);
+        const void* const source[kTableCount] = {p.sc.lights, p.sc.materials, p.sc.meshes,
+            p.sc.textures, p.sc.instances, p.sc.transforms};
+        uint32_t* const words = reinterpret_cast<uint32_t*>(shade_lds);
+        for (uint32_t t = 0; t < kTableCount; ++t) {
+            if (plan.offset[t] == kNotStaged) {
+                continue;
+            }
+            const uint32_t* const src = static_cast<const uint32_t*>(source[t]);
+            for (uint32_t i = threadIdx.x; i < plan.bytes[t] / 4u; i += kShadeThreads) {
+                words[plan.offset[t] / 4u + i] = src[i];
+            }
+        }
+        __syncthreads();
+        auto staged = [&](uint32_t t, const void* fallback) -> const void* {
+            return plan.offset[t] == kNotStaged
+                       ? fallback
+                       : static_cast<const void*>(reinterpret_cast<const char*>(shade_lds) +
+                                                  plan.offset[t]);
+        };
+        sc.lights = static_cast<const rt_light*>(staged(kTableLights, p.sc.lights));
+        sc.materials = static_cast<const rt_material*>(staged(kTableMaterials, p.sc.materials));
+        sc.meshes = static_cast<const rt_mesh*>(staged(kTableMeshes, p.sc.meshes));
+        sc.textures = static_cast<const texture_dev*>(staged(kTableTextures, p.sc.textures));
+        sc.instances = static_cast<const rt_instance*>(staged(kTableInstances, p.sc.instances));
+        sc.transforms = static_cast<const rt_mat4*>(staged(kTableTransforms, p.sc.transforms));
+    }
     const uint32_t* const live = p.live;
-    uint32_t total_hits = 0, total_skipped = 0;
+    uint32_t total_hits = 0, total_skipped = 0, samples = 0;
     for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
         uint32_t const i = chunk * 64u + wave_lane();
-        bool const active = i < n_live;
-        uint32_t const entry = active ? live[i] : 0u;
+        bool const in_range = i < n_live;
+        bool active = in_range;
+        uint32_t const entry = FIRST ? (i | kLiveHasClosest) : (active ? live[i] : 0u);
         uint32_t const pid = entry & kLivePidMask;
         ray_pair rp;
         rp.has_shadow = (entry & kLiveHasShadow) != 0u;
         rp.has_closest = (entry & kLiveHasClosest) != 0u;
         uint32_t closest_hits = 0, shadow_skipped = 0;
+        path_state ps;
+        if (FIRST) {
+            active = primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
+            ps.radiance = splat3(0.0f);
+            ps.throughput = splat3(1.0f);
+            ps.nee = splat3(0.0f);
+            ps.last_bsdf_pdf = 0.0f;
+            ps.depth = 0;
+            samples += active ? 1u : 0u;
+        }
         if (active) {
-            float4 const rad = p.rad[pid];
-            float4 const thr = p.thr[pid];
-            float4 const nee = p.nee[pid];
-            path_state ps;
-            ps.radiance = mk3(rad.x, rad.y, rad.z);
-            ps.depth = __float_as_uint(rad.w);
-            ps.throughput = mk3(thr.x, thr.y, thr.z);
-            ps.seed = __float_as_uint(thr.w);
-            ps.nee = mk3(nee.x, nee.y, nee.z);
-            ps.last_bsdf_pdf = nee.w;
+            if (!FIRST) {
+                float4 const rad = p.rad[pid];
+                float4 const thr = p.thr[pid];
+                float4 const nee = p.nee[pid];
+                ps.radiance = mk3(rad.x, rad.y, rad.z);
+                ps.depth = __float_as_uint(rad.w);
+                ps.throughput = mk3(thr.x, thr.y, thr.z);
+                ps.seed = __float_as_uint(thr.w);
+                ps.nee = mk3(nee.x, nee.y, nee.z);
+                ps.last_bsdf_pdf = nee.w;
+            }
             pair_result pr;
             pr.occluded = rp.has_shadow && p.occluded[pid] != 0u;
             pr.hit = false;
             if (rp.has_closest) {
-                float4 const o = p.ray_o[pid];
-                float4 const d = p.ray_d[pid];
-                rp.origin = mk3(o.x, o.y, o.z);
-                rp.direction = mk3(d.x, d.y, d.z);
+                if (!FIRST) {
+                    float4 const o = p.ray_o[pid];
+                    float4 const d = p.ray_d[pid];
+                    rp.origin = mk3(o.x, o.y, o.z);
+                    rp.direction = mk3(d.x, d.y, d.z);
+                }
                 float4 const h0 = p.hit0[pid];
                 pr.best.instance = __float_as_uint(h0.x);
                 pr.hit = pr.best.instance != RT_HIP_MISS;
@@ -461,7 +566,7 @@ __global__ void __launch_bounds__(64, 2) wf_shade_kernel(wavefront_params const 
                     pr.best.t = h1.y;
                 }
             }
-            shade_trip(p.sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
+            shade_trip(sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
             p.rad[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
                 __uint_as_float(ps.depth));
             if (rp.has_closest || rp.has_shadow) {
@@ -484,7 +589,7 @@ __global__ void __launch_bounds__(64, 2) wf_shade_kernel(wavefront_params const 
             rp.has_closest = false;
         }
         bool const goes_on = rp.has_closest || rp.has_shadow;
-        publish_raw(p, chunk, i, active,
+        publish_raw(p, chunk, i, in_range,
             goes_on ? (pid | (rp.has_closest ? kLiveHasClosest : 0u) |
                           (rp.has_shadow ? kLiveHasShadow : 0u))
                     : 0u);
@@ -493,9 +598,101 @@ __global__ void __launch_bounds__(64, 2) wf_shade_kernel(wavefront_params const 
     }
     unsigned long long const hits = wave_sum(total_hits);
     unsigned long long const skipped = wave_sum(total_skipped);
+    unsigned long long const started = FIRST ? wave_sum(samples) : 0ull;
     if (wave_lane() == 0) {
         add_wave_stat(p, kStatClosestHits, hits);
         add_wave_stat(p, kStatShadowSkipped, skipped);
+        if (FIRST) {
+            add_wave_stat(p, kStatSamples, started);  // = trip 0's closest-hit rays, too
+        }
+    }
+}
+
+// Runs every path that is still alive at trip `trip` to its end inside one kernel, fused-
+// kernel style (trace, shade, trace ... with the path in registers).  After the first
+// bounces few paths are left; giving each of their remaining bounces a trace launch, a
+// shade launch and a compaction costs more in launch tails than the work itself.
+template <int ACCEL, bool COUNT>
+__global__ void __launch_bounds__(64, 2) wf_finish_kernel(wavefront_params const p, uint32_t trip) {
+    __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
+    fast_stack stk{};
+    stk.lds = lds_stack + threadIdx.x;
+    uint32_t const n_live = p.control[trip * kCtlWords + kCtlLive];
+    uint32_t const total_chunks = (n_live + 63u) / 64u;
+    trace_counters cnt;
+    uint32_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, shadow_skipped = 0;
+    for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
+        uint32_t const i = chunk * 64u + wave_lane();
+        bool const active = i < n_live;
+        uint32_t const entry = active ? p.live[i] : 0u;
+        uint32_t const pid = entry & kLivePidMask;
+        ray_pair rp;
+        rp.has_shadow = (entry & kLiveHasShadow) != 0u;
+        rp.has_closest = (entry & kLiveHasClosest) != 0u;
+        path_state ps;
+        ps.radiance = ps.throughput = ps.nee = splat3(0.0f);
+        ps.last_bsdf_pdf = 0.0f;
+        ps.depth = 0;
+        ps.seed = 0;
+        rp.origin = rp.shadow_origin = splat3(0.0f);
+        rp.direction = rp.shadow_direction = mk3(1.0f, 0.0f, 0.0f);
+        rp.shadow_t_max = 1.0f;
+        if (active) {
+            float4 const rad = p.rad[pid];
+            float4 const thr = p.thr[pid];
+            float4 const nee = p.nee[pid];
+            ps.radiance = mk3(rad.x, rad.y, rad.z);
+            ps.depth = __float_as_uint(rad.w);
+            ps.throughput = mk3(thr.x, thr.y, thr.z);
+            ps.seed = __float_as_uint(thr.w);
+            ps.nee = mk3(nee.x, nee.y, nee.z);
+            ps.last_bsdf_pdf = nee.w;
+            if (rp.has_closest) {
+                float4 const o = p.ray_o[pid];
+                float4 const d = p.ray_d[pid];
+                rp.origin = mk3(o.x, o.y, o.z);
+                rp.direction = mk3(d.x, d.y, d.z);
+            }
+            if (rp.has_shadow) {
+                float4 const o = p.sh_o[pid];
+                float4 const d = p.sh_d[pid];
+                rp.shadow_origin = mk3(o.x, o.y, o.z);
+                rp.shadow_direction = mk3(d.x, d.y, d.z);
+                rp.shadow_t_max = o.w;
+            }
+        }
+        while (rp.has_closest || rp.has_shadow) {
+            pair_result pr;
+            closest_rays += rp.has_closest ? 1u : 0u;
+            shadow_rays += rp.has_shadow ? 1u : 0u;
+            trace_pair<ACCEL, COUNT>(p.sc, stk, rp, pr, cnt);
+            shade_trip(p.sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
+        }
+        if (active) {
+            p.rad[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
+                __uint_as_float(ps.depth));
+        }
+    }
+    unsigned long long const sums[4] = {wave_sum(closest_rays), wave_sum(shadow_rays),
+        wave_sum(closest_hits), wave_sum(shadow_skipped)};
+    unsigned long long const nodes = COUNT ? wave_sum(cnt.nodes) : 0ull;
+    unsigned long long const tris = COUNT ? wave_sum(cnt.tris) : 0ull;
+    uint32_t deepest = cnt.max_stack;
+    for (int offset = 32; offset > 0; offset >>= 1) {
+        deepest = max(deepest, (uint32_t) __shfl_down((int) deepest, offset, 64));
+    }
+    if (wave_lane() == 0) {
+        add_wave_stat(p, kStatClosestRays, sums[0]);
+        add_wave_stat(p, kStatShadowRays, sums[1]);
+        add_wave_stat(p, kStatClosestHits, sums[2]);
+        add_wave_stat(p, kStatShadowSkipped, sums[3]);
+        if (COUNT) {
+            add_wave_stat(p, kStatNodes, nodes);
+            add_wave_stat(p, kStatTris, tris);
+            unsigned long long* const slot =
+                p.wave_stats + (size_t) wave_index() * kStatWords + kStatMaxStack;
+            *slot = max(*slot, (unsigned long long) deepest);
+        }
     }
 }
 

@@ -27,7 +27,7 @@ EXPORTS = [
     "rt_hip_render", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes",
-    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_destroy", "rt_hip_last_error",
+    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
 
@@ -76,6 +76,7 @@ def lib():
         l.rt_hip_stats.argtypes = [C.c_void_p, C.POINTER(T.Stats), C.c_int]
         l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
         l.rt_hip_kernel_time_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), u32p]
+        l.rt_hip_trip_counts.argtypes = [C.c_void_p, C.c_uint32, u32p]
         l.rt_hip_destroy.argtypes = [C.c_void_p]
         _lib = l
     return _lib
@@ -165,6 +166,12 @@ class HipRenderer:
         n = C.c_uint32()
         _check(lib().rt_hip_kernel_time_of(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def trip_counts(self, trip):
+        """(live paths, closest-hit rays, occlusion rays) of bounce `trip` in the last batch."""
+        out = (C.c_uint32 * 3)()
+        _check(lib().rt_hip_trip_counts(self._h, trip, out))
+        return tuple(out)
 
     def close(self):
         if self._h:

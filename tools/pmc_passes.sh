@@ -18,13 +18,18 @@ for CTRS in \
   timeout -s KILL 120 rocprofv3 --pmc $CTRS --output-format csv -d $ROOT/gpurun_out/${OUT}_p$i -o p -- python3 $ROOT/bench.py --no-cpu-baseline --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${OUT}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $ROOT/gpurun_out/${OUT}_p$i.log; exit 1; }
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
+# per kernel (short name): counter -> sum over the launches of the last profiled step
 for d in sorted(glob.glob("$ROOT/gpurun_out/${OUT}_p*/")):
     for f in glob.glob(d + "*counter_collection.csv"):
-        acc = collections.defaultdict(list)
+        acc = collections.defaultdict(lambda: collections.defaultdict(float))
+        n = collections.Counter()
         for row in csv.DictReader(open(f)):
-            if "path_trace" in row["Kernel_Name"]:
-                acc[row["Counter_Name"]].append(float(row["Counter_Value"]))
-        for k, v in acc.items():
-            print(k, "n=%d" % len(v), "last=%.6g" % v[-1], "mean=%.6g" % (sum(v) / len(v)))
+            m = re.search(r"(path_trace_kernel|wf_[a-z_]+_kernel)", row["Kernel_Name"])
+            if not m:
+                continue
+            acc[m.group(1)][row["Counter_Name"]] += float(row["Counter_Value"])
+            n[(m.group(1), row["Counter_Name"])] += 1
+        for k in sorted(acc):
+            print(k, " ".join("%s=%.4g(n=%d)" % (c, v, n[(k, c)]) for c, v in sorted(acc[k].items())))
 PY
