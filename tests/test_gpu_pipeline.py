@@ -1,0 +1,133 @@
+"""rt_hip_render runs as a pipeline of trace / shade launches per bounce (queues in device
+memory, LDS-cached traversal, a finishing kernel for the late bounces).  The single fused
+kernel (RT_HIP_FLAG_FUSED, also what rt_hip_render_tile uses) computes every path with the
+same device functions in the same order, so the two must agree bit for bit - images and work
+counters - in both acceleration-structure modes, across batch boundaries and for deep paths."""
+import numpy as np
+import pytest
+
+from raytracing_amd import hip, host
+
+pytestmark = pytest.mark.gpu
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def run(scene, w, h, md, tile, spp, accel, flags, rect=None):
+    r = hip.HipRenderer(w, h, md, tile, accel=accel, flags=flags)
+    try:
+        r.upload_scene(scene.desc)
+        r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+        r.clear()
+        r.render(scene.camera(w, h), 0, spp, rect=rect)
+        img, passes = r.read_accum()
+        st = r.stats()
+        return img, passes, st
+    finally:
+        r.close()
+
+
+COUNTERS = ["samples", "closest_rays", "shadow_rays", "closest_hits", "shadow_skipped",
+            "nodes_visited", "tris_tested", "max_stack"]
+
+
+@pytest.mark.parametrize("accel", [hip.ACCEL_REFERENCE, hip.ACCEL_REBUILT])
+@pytest.mark.parametrize("scene_name", ["cornell", "hyperion"])
+def test_pipeline_equals_fused_kernel(request, scene_name, accel):
+    scene = request.getfixturevalue(scene_name)
+    w, h, md, tile, spp = 320, 184, 7, (64, 46), 5   # 184 = 23 * 8; tiles of 64 x 46
+    fused = run(scene, w, h, md, tile, spp, accel, hip.FLAG_FUSED | hip.FLAG_COUNT_NODES)
+    piped = run(scene, w, h, md, tile, spp, accel, hip.FLAG_COUNT_NODES)
+    assert fused[1] == piped[1] == spp
+    assert same(fused[0], piped[0])
+    for k in COUNTERS:
+        assert fused[2][k] == piped[2][k], k
+
+
+def test_pipeline_partial_blocks(cornell):
+    """A rectangle whose sides are not multiples of the 8x8 path blocks: the padding lanes of
+    the edge blocks start no path and touch no pixel."""
+    w, h, md, tile, spp = 320, 180, 5, (64, 36), 3
+    rect = (5, 3, 299, 171)
+    fused = run(cornell, w, h, md, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_FUSED, rect)
+    piped = run(cornell, w, h, md, tile, spp, hip.ACCEL_REBUILT, 0, rect)
+    assert same(fused[0], piped[0])
+    assert piped[2]["samples"] == (299 - 5) * (171 - 3) * spp
+    assert (piped[0][:3, :, :3] == 0).all() and (piped[0][:, :5, :3] == 0).all()
+
+
+def test_deep_paths_through_the_finishing_kernel(cornell):
+    """max_depth 24: bounces 4.. are run by the finishing kernel, 20 of them."""
+    w, h, tile, spp = 160, 96, (32, 24), 4
+    fused = run(cornell, w, h, 24, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_FUSED)
+    piped = run(cornell, w, h, 24, tile, spp, hip.ACCEL_REBUILT, 0)
+    assert same(fused[0], piped[0])
+    for k in ["samples", "closest_rays", "shadow_rays", "closest_hits", "shadow_skipped"]:
+        assert fused[2][k] == piped[2][k], k
+    assert piped[2]["closest_rays"] > 3.5 * piped[2]["samples"]  # the paths really are long
+
+
+def test_shallow_depths(cornell):
+    """max_depth 0 and 1: fewer bounces than the pipeline has stages."""
+    for md in (0, 1, 2):
+        fused = run(cornell, 160, 96, md, (32, 24), 2, hip.ACCEL_REBUILT, hip.FLAG_FUSED)
+        piped = run(cornell, 160, 96, md, (32, 24), 2, hip.ACCEL_REBUILT, 0)
+        assert same(fused[0], piped[0]), md
+        assert fused[2]["closest_rays"] == piped[2]["closest_rays"], md
+        assert fused[2]["shadow_rays"] == piped[2]["shadow_rays"], md
+
+
+def test_batches_of_passes(hyperion):
+    """1280x720 x 40 passes = 36.9 M paths: more than one batch of 2^25 paths.  One call must
+    equal the same passes given in two calls (which also splits the batches elsewhere)."""
+    w, h, md, tile, spp = 1280, 720, 3, (128, 72), 40
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+        cam = hyperion.camera(w, h)
+        r.clear()
+        r.render(cam, 0, spp)
+        one, passes = r.read_accum()
+        assert passes == spp
+        assert r.stats(reset=True)["samples"] == w * h * spp
+        r.clear()
+        r.render(cam, 0, 17)
+        r.render(cam, 17, 23)
+        two, _ = r.read_accum()
+        assert same(one, two)
+    finally:
+        r.close()
+
+
+def test_trip_counts_and_kernel_times(hyperion):
+    w, h, md, tile, spp = 640, 360, 7, (64, 36), 4
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_TIME_KERNELS)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+        r.clear()
+        r.render(hyperion.camera(w, h), 0, spp)
+        st = r.stats()
+        counts = [r.trip_counts(t) for t in range(md + 1)]
+        assert counts[0] == (w * h * spp, w * h * spp, 0)
+        live = [c[0] for c in counts]
+        # paths only die; bounces handed to the finishing kernel report nothing
+        handed_over = next((t for t in range(1, md + 1) if live[t] == 0), md + 1)
+        assert all(live[t] >= live[t + 1] for t in range(handed_over - 1))
+        assert all(c == (0, 0, 0) for c in counts[handed_over + 1:])
+        assert sum(c[1] for c in counts) <= st["closest_rays"]
+        assert sum(c[2] for c in counts) <= st["shadow_rays"]
+        # every path of bounce t has a closest-hit ray, an occlusion ray or both
+        assert all(max(c[1], c[2]) <= c[0] <= c[1] + c[2] for c in counts)
+        whole_ms, calls = r.kernel_time(hip.KERNEL_RENDER)
+        extend_ms, extends = r.kernel_time(hip.KERNEL_EXTEND)
+        shade_ms, shades = r.kernel_time(hip.KERNEL_SHADE)
+        assert calls == 1 and extends == shades and 1 <= extends <= md + 1
+        assert 0.0 < extend_ms * extends + shade_ms * shades <= whole_ms
+        with pytest.raises(RuntimeError):
+            r.trip_counts(md + 5)
+    finally:
+        r.close()
