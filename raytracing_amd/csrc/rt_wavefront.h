@@ -99,6 +99,33 @@ struct wavefront_params {
 
 RT_DEV uint32_t wave_lane() { return threadIdx.x & 63u; }
 
+// Path state and queues are streamed: written by one launch, read once by the next, with
+// gigabytes of other traffic in between.  Non-temporal accesses keep them from evicting the
+// BVH and the triangles from the L2, which every ray re-reads.
+typedef float native_f4 __attribute__((ext_vector_type(4)));
+typedef float native_f2 __attribute__((ext_vector_type(2)));
+
+RT_DEV float4 stream_load(const float4* p) {
+    native_f4 const v = __builtin_nontemporal_load(reinterpret_cast<const native_f4*>(p));
+    return make_float4(v.x, v.y, v.z, v.w);
+}
+RT_DEV float2 stream_load(const float2* p) {
+    native_f2 const v = __builtin_nontemporal_load(reinterpret_cast<const native_f2*>(p));
+    return make_float2(v.x, v.y);
+}
+RT_DEV uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+RT_DEV void stream_store(float4* p, float4 v) {
+    native_f4 n;
+    n.x = v.x, n.y = v.y, n.z = v.z, n.w = v.w;
+    __builtin_nontemporal_store(n, reinterpret_cast<native_f4*>(p));
+}
+RT_DEV void stream_store(float2* p, float2 v) {
+    native_f2 n;
+    n.x = v.x, n.y = v.y;
+    __builtin_nontemporal_store(n, reinterpret_cast<native_f2*>(p));
+}
+RT_DEV void stream_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(v, p); }
+
 // Index of this wave in its launch and the number of waves launched.
 RT_DEV uint32_t wave_index() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
 RT_DEV uint32_t wave_total() { return (gridDim.x * blockDim.x) >> 6; }
@@ -389,7 +416,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         if (chunk < closest_chunks) {
             uint32_t const i = chunk * 64u + wave_lane();
             bool active = i < n_closest;
-            uint32_t const pid = FIRST ? i : (active ? q_closest[i] : 0u);
+            uint32_t const pid = FIRST ? i : (active ? stream_load(&q_closest[i]) : 0u);
             float4 o = make_float4(0.0f, 0.0f, 0.0f, 0.0f), d = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
             if (FIRST) {
                 uint32_t seed;
@@ -400,8 +427,8 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                     d = make_float4(direction.x, direction.y, direction.z, 0.0f);
                 }
             } else if (active) {
-                o = p.ray_o[pid];
-                d = p.ray_d[pid];
+                o = stream_load(&p.ray_o[pid]);
+                d = stream_load(&p.ray_d[pid]);
             }
             hit_result best;
             best.instance = RT_HIP_MISS;
@@ -417,18 +444,19 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                                     mk3(d.x, d.y, d.z), kInfinity, best, cnt);
             }
             if (active) {
-                p.hit0[pid] = make_float4(__uint_as_float(hit ? best.instance : RT_HIP_MISS),
-                    __uint_as_float(best.triangle), best.b0, best.b1);
-                p.hit1[pid] = make_float2(best.b2, best.t);
+                stream_store(&p.hit0[pid],
+                    make_float4(__uint_as_float(hit ? best.instance : RT_HIP_MISS),
+                        __uint_as_float(best.triangle), best.b0, best.b1));
+                stream_store(&p.hit1[pid], make_float2(best.b2, best.t));
             }
         } else {
             uint32_t const i = (chunk - closest_chunks) * 64u + wave_lane();
             bool const active = i < n_shadow;
-            uint32_t const pid = active ? q_shadow[i] : 0u;
+            uint32_t const pid = active ? stream_load(&q_shadow[i]) : 0u;
             float4 o = make_float4(0.0f, 0.0f, 0.0f, 1.0f), d = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
             if (active) {
-                o = p.sh_o[pid];
-                d = p.sh_d[pid];
+                o = stream_load(&p.sh_o[pid]);
+                d = stream_load(&p.sh_d[pid]);
             }
             hit_result unused;
             bool blocked;
@@ -440,7 +468,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                                         mk3(d.x, d.y, d.z), o.w, unused, cnt);
             }
             if (active) {
-                p.occluded[pid] = blocked ? 1u : 0u;
+                stream_store(&p.occluded[pid], blocked ? 1u : 0u);
             }
         }
     }
