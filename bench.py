@@ -64,6 +64,22 @@ def load_constants(scene_name):
         return json.load(f)[scene_name]
 
 
+def measured_traffic(kernel, args):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (tools/pmc_passes.sh:
+    FETCH_SIZE doubled as the gfx950 counter requires, plus WRITE_SIZE), or None when no
+    measurement of this exact workload is on file.  bench.py cannot collect counters itself."""
+    path = os.path.join(ROOT, "profiles", "r01", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    same = (t.get("scene") == args.scene and t.get("width") == args.width
+            and t.get("height") == args.height and t.get("max_depth") == args.max_depth
+            and t.get("spp_per_step") == args.spp_per_step and t.get("pipeline") == args.pipeline
+            and t.get("accel") == args.accel)
+    return t.get("bytes_per_launch", {}).get(kernel) if same else None
+
+
 def cpu_baseline(sc, cam, args, tile, target_seconds):
     """Times the CPU restatement (the oracle) on a bounded sample of the same workload."""
     import oracle
@@ -177,20 +193,29 @@ def main():
                 bytes_l = (trace_bytes + shade_bytes + frame_bytes) / n
                 extra = {}
             else:
-                # the dominant kernel of the pipeline is the trace launch (one per bounce)
+                # the dominant kernel of the pipeline is the trace launch (one per bounce);
+                # late bounces are handed to a finishing kernel, whose rays do not count here
                 ms, n = r.kernel_time(hip.KERNEL_EXTEND)
                 shade_ms, shade_n = r.kernel_time(hip.KERNEL_SHADE)
                 name = "wf_extend_kernel"
-                bytes_l = trace_bytes / max(n, 1)
-                extra = {"rays_per_bounce": [sum(r.trip_counts(t)[1:])
-                                             for t in range(args.max_depth + 1)],
+                per_call = n // max(launches, 1)
+                per_bounce = [sum(r.trip_counts(t)[1:]) for t in range(args.max_depth + 1)]
+                traced = sum(per_bounce[:per_call]) * launches  # every call traces the same counts +- noise
+                per_ray = k["nodes_per_ray"] * NODE_BYTES + k["tris_per_ray"] * TRI_BYTES
+                bytes_l = traced * per_ray / max(n, 1)
+                extra = {"rays_per_bounce_last_call": per_bounce,
+                         "trace_launches_per_call": per_call,
                          "render_call_avg_ms": kernel_ms, "render_calls": launches,
                          "shade_kernel_avg_ms": shade_ms, "shade_launches": shade_n,
                          "extend_ms_per_call": ms * n / launches,
-                         "shade_ms_per_call": shade_ms * shade_n / launches}
+                         "shade_ms_per_call": shade_ms * shade_n / launches,
+                         "whole_call_algorithmic_gbs":
+                             (trace_bytes + shade_bytes + frame_bytes) / launches
+                             / (kernel_ms * 1e-3) / 1e9}
             achieved = bytes_l / (ms * 1e-3) / 1e9
             roofline = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS,
-                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                        "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "traffic": measured_traffic(name, args),
                         "kernel": name, "kernel_avg_ms": ms, "launches": n,
                         "algorithmic_bytes_per_launch": bytes_l, **extra}
         cpu = None

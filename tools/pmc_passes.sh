@@ -32,4 +32,9 @@ for d in sorted(glob.glob("$ROOT/gpurun_out/${OUT}_p*/")):
             n[(m.group(1), row["Counter_Name"])] += 1
         for k in sorted(acc):
             print(k, " ".join("%s=%.4g(n=%d)" % (c, v, n[(k, c)]) for c, v in sorted(acc[k].items())))
+            for c in ("FETCH_SIZE", "WRITE_SIZE"):
+                if c in acc[k]:
+                    # rocprofv3 reports kilobytes; gfx950 FETCH_SIZE counts 64 B per 128-B request
+                    per_launch = acc[k][c] * 1024.0 * (2.0 if c == "FETCH_SIZE" else 1.0) / n[(k, c)]
+                    print("  %s %s bytes per launch (corrected) = %.4g" % (k, c, per_launch))
 PY
