@@ -569,9 +569,6 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
     }
 }
 
-// Bounce from which the pipeline hands the surviving paths to wf_finish_kernel.
-constexpr uint32_t kWavefrontFinishTrip = 4;
-
 // Paths in flight per batch of the wavefront pipeline: 2^25 paths = 4.6 GB of state.
 constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 25;
 
@@ -718,13 +715,12 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         }
         HIP_CHECK(hipGetLastError());
     };
-    // From this trip on the surviving paths are finished by one fused launch.
-    static uint32_t const finish_trip_setting = [] {
-        char const* v = getenv("RT_HIP_FINISH_TRIP");  // tuning knob
-        return v ? (uint32_t) std::max(0, atoi(v)) : kWavefrontFinishTrip;
+    // Paths alive below which a batch is handed to the finishing kernel (decided on the
+    // device after every compaction): 2 % of the batch, at least a GPU's worth of lanes.
+    static int const handover_setting = [] {
+        char const* v = getenv("RT_HIP_HANDOVER_BELOW");  // tuning knob: absolute path count
+        return v ? atoi(v) : -1;
     }();
-    // trip 0 always runs as launches (the finishing kernel starts from stored path state)
-    uint32_t const finish_trip = std::max(1u, finish_trip_setting);
     auto finish = [&](uint32_t trip, uint32_t chunk_bound) {
         dim3 const grid(std::max(1u, std::min(r.wf_finish_grid, chunk_bound)));
         if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
@@ -748,13 +744,13 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     };
     // Builds trip `trip`'s lists from the raw slots its producer left behind.
     auto compact = [&](uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count,
-                       uint32_t chunk_bound, bool count_rays) {
+                       uint32_t chunk_bound, uint32_t handover_below) {
         dim3 const tiles(std::max(1u, (chunk_bound + kTileChunks - 1u) / kTileChunks));
         hipLaunchKernelGGL(wf_tile_sums_kernel, tiles, dim3(kTileThreads), 0, stream, w,
             in_count_ptr, in_count);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(wf_scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, stream, w, trip,
-            in_count_ptr, in_count, count_rays ? 1u : 0u);
+            in_count_ptr, in_count, handover_below);
         HIP_CHECK(hipGetLastError());
         hipLaunchKernelGGL(wf_scatter_kernel, tiles, dim3(kTileThreads), 0, stream, w,
             in_count_ptr, in_count);
@@ -768,10 +764,12 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         size_t const paths = per_pass * w.pass_count;
         uint32_t const chunk_bound = (uint32_t) (paths / 64u);
         HIP_CHECK(hipMemsetAsync(w.control, 0, (size_t) (trips + 1u) * kCtlWords * 4, stream));
+        uint32_t const handover_below =
+            handover_setting >= 0 ? (uint32_t) handover_setting
+                                  : (uint32_t) std::max<size_t>(paths / 50u, 65536u);
         for (uint32_t trip = 0; trip < trips; ++trip) {
-            if (trip == finish_trip) {
-                finish(trip, chunk_bound);
-                break;
+            if (trip > 0u) {
+                finish(trip, chunk_bound);  // a no-op unless the compaction handed over
             }
             // a trip has at most one closest-hit and one occlusion ray per path
             dim3 const shade_grid(std::min(r.wf_shade_grid,
@@ -800,7 +798,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                 // nothing survives the last trip: its paths are at max_depth
                 // trip 0 publishes one raw slot per path, later trips one per live path
                 compact(trip + 1u, trip == 0u ? nullptr : w.control + trip * kCtlWords + kCtlLive,
-                    (uint32_t) paths, chunk_bound, trip + 1u != finish_trip);
+                    (uint32_t) paths, chunk_bound, handover_below);
             }
         }
         hipLaunchKernelGGL(wf_resolve_kernel, dim3((uint32_t) ((per_pass + 255u) / 256u)),

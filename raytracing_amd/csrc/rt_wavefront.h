@@ -39,6 +39,7 @@ enum : uint32_t {
     kCtlLive = 0,     // entries in this trip's live list
     kCtlClosest = 1,  // entries in this trip's closest-hit ray queue
     kCtlShadow = 2,   // entries in this trip's occlusion ray queue
+    kCtlFinish = 3,   // entries of the live list handed to the finishing kernel instead
     kCtlWords = 4,
 };
 
@@ -264,10 +265,13 @@ __global__ void __launch_bounds__(kTileThreads) wf_tile_sums_kernel(wavefront_pa
     }
 }
 
-// count_rays: the trip's rays are traced by per-trip launches (not by the finishing kernel,
-// which counts its own).
+// handover_below: when fewer paths than this are alive, the trip and all later ones are handed
+// to the finishing kernel: the list lengths that the trace and shade launches read become
+// zero (they and every later launch of the batch return at once) and kCtlFinish holds the
+// length of the live list instead.  Whether few paths are left after two bounces or after ten
+// depends on the scene; the host cannot know without reading back.
 __global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_params const p,
-    uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count, uint32_t count_rays) {
+    uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count, uint32_t handover_below) {
     __shared__ uint32_t scratch[3][kScanThreads];
     uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
     uint32_t const chunks = (n + 63u) / 64u;
@@ -285,11 +289,14 @@ __global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_p
     }
     if (t == kScanThreads - 1u) {
         uint32_t* const ctl = p.control + trip * kCtlWords;
-        ctl[kCtlLive] = incl.live;
-        ctl[kCtlClosest] = incl.closest;
-        ctl[kCtlShadow] = incl.shadow;
-        // single thread of a single workgroup, launches of one renderer are stream-ordered
-        if (count_rays != 0u) {
+        bool const handover = incl.live < handover_below;
+        ctl[kCtlLive] = handover ? 0u : incl.live;
+        ctl[kCtlClosest] = handover ? 0u : incl.closest;
+        ctl[kCtlShadow] = handover ? 0u : incl.shadow;
+        ctl[kCtlFinish] = handover ? incl.live : 0u;
+        if (!handover) {
+            // the finishing kernel counts the rays it traces itself; single thread of a
+            // single workgroup, and launches of one renderer are stream-ordered
             p.counters[1] += incl.closest;
             p.counters[2] += incl.shadow;
         }
@@ -636,16 +643,20 @@ __global__ void __launch_bounds__(kShadeThreads, 2)
     }
 }
 
-// Runs every path that is still alive at trip `trip` to its end inside one kernel, fused-
-// kernel style (trace, shade, trace ... with the path in registers).  After the first
-// bounces few paths are left; giving each of their remaining bounces a trace launch, a
-// shade launch and a compaction costs more in launch tails than the work itself.
+// Runs every path handed over at trip `trip` (kCtlFinish, see wf_scan_tiles_kernel) to its
+// end inside one kernel, fused-kernel style (trace, shade, trace ... with the path in
+// registers).  Once few paths are left, giving each of their remaining bounces a trace
+// launch, a shade launch and a compaction costs more in launch tails than the work itself.
+// Launched after every compaction; returns at once unless that compaction handed over.
 template <int ACCEL, bool COUNT>
 __global__ void __launch_bounds__(64, 2) wf_finish_kernel(wavefront_params const p, uint32_t trip) {
     __shared__ uint32_t lds_stack[ACCEL == RT_HIP_ACCEL_REBUILT ? kFastLdsEntries * 64u : 64u];
     fast_stack stk{};
     stk.lds = lds_stack + threadIdx.x;
-    uint32_t const n_live = p.control[trip * kCtlWords + kCtlLive];
+    uint32_t const n_live = p.control[trip * kCtlWords + kCtlFinish];
+    if (n_live == 0u) {
+        return;
+    }
     uint32_t const total_chunks = (n_live + 63u) / 64u;
     trace_counters cnt;
     uint32_t closest_rays = 0, shadow_rays = 0, closest_hits = 0, shadow_skipped = 0;

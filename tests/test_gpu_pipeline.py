@@ -59,7 +59,8 @@ def test_pipeline_partial_blocks(cornell):
 
 
 def test_deep_paths_through_the_finishing_kernel(cornell):
-    """max_depth 24: bounces 4.. are run by the finishing kernel, 20 of them."""
+    """max_depth 24 on a small frame (61 440 paths, below the hand-over threshold): after
+    bounce 0 the finishing kernel runs the paths to their end, up to 24 more bounces."""
     w, h, tile, spp = 160, 96, (32, 24), 4
     fused = run(cornell, w, h, 24, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_FUSED)
     piped = run(cornell, w, h, 24, tile, spp, hip.ACCEL_REBUILT, 0)
