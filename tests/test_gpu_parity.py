@@ -34,7 +34,8 @@ def make_renderer(sc, w, h, md, tile, accel, flags=0):
 
 
 def assert_image_close(got, want, what=""):
-    # NaN radiance is a property of the shader: it must appear in the
+    # NaN radiance is a property of the shader (an edge-on light sample has pdf = inf, and
+    # power_heuristic(inf, x) is NaN): it must appear in the
     # same pixels on both sides; everything else must be finite and close
     assert (np.isnan(got) == np.isnan(want)).mean() >= 1 - 1e-5, what
     keep = ~(np.isnan(got) | np.isnan(want)).any(axis=2)
