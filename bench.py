@@ -61,7 +61,7 @@ def parse_args():
 def load_constants(scene_name):
     path = os.path.join(ROOT, "tests", "golden", "workload_constants.json")
     with open(path) as f:
-        return json.load(f)[scene_name]
+        return json.load(f).get(scene_name)
 
 
 def measured_traffic(kernel, args):
@@ -178,8 +178,7 @@ def main():
 
     if rank == 0:
         nan_pixels = int(torch.isnan(accum).any(dim=2).sum().item())
-        k = load_constants(args.scene) if args.scene in ("cornell_box", "hyperion_rect_light") \
-            else None
+        k = load_constants(args.scene)
         roofline = None
         if k is not None and launches > 0:
             # rays counted on the device x the reference-BVH per-ray node/triangle counts

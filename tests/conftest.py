@@ -46,6 +46,14 @@ def hyperion():
 
 
 @pytest.fixture(scope="session")
+def mustang():
+    """assets/mustang_red.json reduced to the five meshes the reference ships, under a
+    substitute environment map (tools/make_fixtures.py: reduced_mustang)."""
+    from raytracing_amd import scenes
+    return scenes.load_snapshot("mustang_red_reduced")
+
+
+@pytest.fixture(scope="session")
 def textured(tmp_path_factory):
     from raytracing_amd import host, scenes
     d = tmp_path_factory.mktemp("textured")

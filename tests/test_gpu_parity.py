@@ -92,15 +92,22 @@ def test_primary_ids_hyperion(hyperion, accel):
 
 
 @pytest.mark.parametrize("accel", ACCELS)
+def test_primary_ids_mustang(mustang, accel):
+    # 46 k triangles in five meshes; the reference BLAS of the glass mesh is 96 levels deep
+    check_ids(mustang, 640, 360, (128, 72), accel)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
 def test_primary_ids_instanced_scene_beyond_reference_limits(instanced, accel):
     # 1604 instances: rays cross far more than the shader's 15-entry candidate list
     check_ids(instanced, 320, 180, (64, 36), accel)
 
 
 @pytest.mark.parametrize("accel", ACCELS)
-@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light"])
-def test_golden_fixture(name, accel, cornell, hyperion):
-    sc = cornell if name == "cornell_box" else hyperion
+@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light", "mustang_red_reduced"])
+def test_golden_fixture(name, accel, cornell, hyperion, mustang):
+    sc = {"cornell_box": cornell, "hyperion_rect_light": hyperion,
+          "mustang_red_reduced": mustang}[name]
     z = np.load(os.path.join(GOLDEN, f"oracle_{name}.npz"))
     w, h, tw, th, spp, md = (int(v) for v in z["params"])
     seeds = host.seed_schedule(0, spp, (w // tw) * (h // th))

@@ -18,9 +18,10 @@ def load_golden(name):
     return z, w, h, (tw, th), spp, md
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light"])
-def test_oracle_reproduces_golden_bit_for_bit(name, cornell, hyperion):
-    sc = cornell if name == "cornell_box" else hyperion
+@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light", "mustang_red_reduced"])
+def test_oracle_reproduces_golden_bit_for_bit(name, cornell, hyperion, mustang):
+    sc = {"cornell_box": cornell, "hyperion_rect_light": hyperion,
+          "mustang_red_reduced": mustang}[name]
     z, w, h, tile, spp, md = load_golden(name)
     seeds = host.seed_schedule(0, spp, (w // tile[0]) * (h // tile[1]))
     cam = sc.camera(w, h)

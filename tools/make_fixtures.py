@@ -1,7 +1,8 @@
 """Regenerates everything under tests/golden/ (run in the build container, needs the
 reference checkout at /root/reference for the asset files and its screenshot).
 
-  scenes/<name>.rtsnap        loader output for the reference's shipped scenes
+  scenes/<name>.rtsnap        loader output for the reference's shipped scenes (mustang_red
+                              reduced to the meshes that ship, see reduced_mustang)
   oracle_<name>.npz           small fixed-seed oracle renders + primary-hit id maps
   ref_hyperion_thumb.png      down-scaled copy of the reference's own screenshot
                               (outputs/hyperion_rect_light.png), the only output of the
@@ -15,6 +16,7 @@ the HIP kernels) against regressions, they are NOT outputs of the reference.
 import json
 import os
 import sys
+import tempfile
 
 import numpy as np
 
@@ -31,14 +33,38 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 SMALL = {
     "cornell_box": (96, 96, (24, 24), 4, 3),
     "hyperion_rect_light": (160, 90, (32, 18), 4, 5),
+    "mustang_red_reduced": (160, 90, (32, 18), 4, 7),
 }
+
+
+def reduced_mustang(directory):
+    """assets/mustang_red.json as far as it can be loaded: the five primitives whose meshes
+    ship with the reference (floor plane, glass, headlights, blinkers, tail lights: spec_trans
+    glass, rough transmission and metal materials under an environment map) and
+    textures/computer_room.hdr in place of the missing HDR/leadenhall_market.hdr.  Camera,
+    materials, renderer block and sky intensity are the file's own."""
+    with open(os.path.join(REF, "assets", "mustang_red.json")) as f:
+        scene = json.load(f)
+    scene["primitive"] = {k: v for k, v in scene["primitive"].items()
+                          if os.path.exists(os.path.join(REF, "assets", v["mesh"]))}
+    scene["sky_light"]["environment_tex"] = "textures/computer_room.hdr"
+    for sub in ("Mustang", "textures"):
+        os.symlink(os.path.join(REF, "assets", sub), os.path.join(directory, sub))
+    path = os.path.join(directory, "mustang_red_reduced.json")
+    with open(path, "w") as f:
+        json.dump(scene, f)
+    return path
 
 
 def main():
     os.makedirs(os.path.join(GOLDEN, "scenes"), exist_ok=True)
     constants = {}
+    scratch = tempfile.TemporaryDirectory()
     for name, (w, h, tile, spp, md) in SMALL.items():
-        sc = host.HostScene.from_json(os.path.join(REF, "assets", name + ".json"))
+        if name == "mustang_red_reduced":
+            sc = host.HostScene.from_json(reduced_mustang(scratch.name))
+        else:
+            sc = host.HostScene.from_json(os.path.join(REF, "assets", name + ".json"))
         sc.save_snapshot(os.path.join(GOLDEN, "scenes", name + ".rtsnap"))
         cam = sc.camera(w, h)
         tiles = (w // tile[0]) * (h // tile[1])
