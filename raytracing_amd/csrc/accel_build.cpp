@@ -50,8 +50,14 @@ struct build_prim {
     uint32_t id;
 };
 
+// Node of the binary tree the SAH builder produces; collapsed into wide_node afterwards.
+struct bin_node {
+    box3 b0, b1;
+    int32_t child0, child1;
+};
+
 constexpr int kBins = 16;
-constexpr uint32_t kStackEntries = 32;  // = kFastLdsEntries of the traversal kernel
+constexpr uint32_t kStackEntries = 40;  // = kFastLdsEntries of the traversal kernels
 constexpr float kTraversalCost = 1.2f;
 constexpr float kIntersectCost = 1.0f;
 
@@ -66,7 +72,7 @@ public:
     // more than depth_limit pending siblings.  A subtree whose remaining levels would not
     // suffice for SAH's uneven splits is split by object median from there on.
     template <typename EMIT>
-    int32_t build(std::vector<wide_node>& nodes, build_prim* prims, uint32_t count,
+    int32_t build(std::vector<bin_node>& nodes, build_prim* prims, uint32_t count,
         uint32_t max_leaf, uint32_t depth, uint32_t depth_limit, EMIT& emit_leaf,
         uint32_t& deepest) {
         if (count <= max_leaf &&
@@ -86,7 +92,7 @@ public:
         }
         uint32_t const mid = partition(prims, count, needed + 1u >= levels_left);
         uint32_t const self = (uint32_t) nodes.size();
-        nodes.push_back(wide_node{});
+        nodes.push_back(bin_node{});
         box3 b0, b1;
         for (uint32_t i = 0; i < mid; ++i) {
             b0.grow(prims[i].bounds);
@@ -98,11 +104,9 @@ public:
             build(nodes, prims, mid, max_leaf, depth + 1, depth_limit, emit_leaf, deepest);
         int32_t const c1 = build(
             nodes, prims + mid, count - mid, max_leaf, depth + 1, depth_limit, emit_leaf, deepest);
-        wide_node& n = nodes[self];
-        n.lo0x = b0.lo[0]; n.lo0y = b0.lo[1]; n.lo0z = b0.lo[2];
-        n.hi0x = b0.hi[0]; n.hi0y = b0.hi[1]; n.hi0z = b0.hi[2];
-        n.lo1x = b1.lo[0]; n.lo1y = b1.lo[1]; n.lo1z = b1.lo[2];
-        n.hi1x = b1.hi[0]; n.hi1y = b1.hi[1]; n.hi1z = b1.hi[2];
+        bin_node& n = nodes[self];
+        n.b0 = b0;
+        n.b1 = b1;
         n.child0 = c0;
         n.child1 = c1;
         return (int32_t) self;
@@ -222,18 +226,68 @@ private:
     }
 };
 
-float child_area(wide_node const& n, int child) {
-    float const dx = child == 0 ? n.hi0x - n.lo0x : n.hi1x - n.lo1x;
-    float const dy = child == 0 ? n.hi0y - n.lo0y : n.hi1y - n.lo1y;
-    float const dz = child == 0 ? n.hi0z - n.lo0z : n.hi1z - n.lo1z;
-    return dx * dy + dy * dz + dz * dx;
+box3 child_box(wide_node const& n, int c) {
+    box3 b;
+    b.lo[0] = n.lo_x[c], b.lo[1] = n.lo_y[c], b.lo[2] = n.lo_z[c];
+    b.hi[0] = n.hi_x[c], b.hi[1] = n.hi_y[c], b.hi[2] = n.hi_z[c];
+    return b;
 }
 
-float union_area(wide_node const& n) {
-    float const dx = std::max(n.hi0x, n.hi1x) - std::min(n.lo0x, n.lo1x);
-    float const dy = std::max(n.hi0y, n.hi1y) - std::min(n.lo0y, n.lo1y);
-    float const dz = std::max(n.hi0z, n.hi1z) - std::min(n.lo0z, n.lo1z);
-    return dx * dy + dy * dz + dz * dx;
+// Collapses the binary tree under `root` into wide nodes: the children of a wide node are
+// found by repeatedly opening the inner child with the largest surface area, up to `arity`
+// children.  Returns the reference of the collapsed root; `need` = stack entries a walk of
+// this tree can have pending at once (sum over the deepest path of children - 1).
+int32_t collapse(std::vector<bin_node> const& bin, int32_t root, uint32_t arity,
+    std::vector<wide_node>& out, uint32_t& need) {
+    if (root < 0) {
+        need = 0;
+        return root;  // a tree that is a single leaf
+    }
+    struct pending {
+        int32_t ref;
+        box3 box;
+    };
+    pending kids[4];
+    uint32_t count = 2;
+    kids[0] = {bin[(size_t) root].child0, bin[(size_t) root].b0};
+    kids[1] = {bin[(size_t) root].child1, bin[(size_t) root].b1};
+    while (count < arity) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (uint32_t i = 0; i < count; ++i) {
+            if (kids[i].ref >= 0 && kids[i].box.half_area() > best_area) {
+                best_area = kids[i].box.half_area();
+                best = (int) i;
+            }
+        }
+        if (best < 0) {
+            break;
+        }
+        bin_node const& open = bin[(size_t) kids[best].ref];
+        kids[best] = {open.child0, open.b0};
+        kids[count++] = {open.child1, open.b1};
+    }
+    uint32_t const self = (uint32_t) out.size();
+    out.push_back(wide_node{});
+    wide_node n{};
+    uint32_t deepest = 0;
+    for (uint32_t i = 0; i < 4; ++i) {
+        if (i < count) {
+            n.lo_x[i] = kids[i].box.lo[0], n.lo_y[i] = kids[i].box.lo[1], n.lo_z[i] = kids[i].box.lo[2];
+            n.hi_x[i] = kids[i].box.hi[0], n.hi_y[i] = kids[i].box.hi[1], n.hi_z[i] = kids[i].box.hi[2];
+            uint32_t child_need = 0;
+            n.child[i] = collapse(bin, kids[i].ref, arity, out, child_need);
+            deepest = std::max(deepest, child_need);
+        } else {
+            // inverted box: no ray interval can be non-empty
+            n.lo_x[i] = n.lo_y[i] = n.lo_z[i] = std::numeric_limits<float>::max();
+            n.hi_x[i] = n.hi_y[i] = n.hi_z[i] = std::numeric_limits<float>::lowest();
+            n.child[i] = kNoChild;
+        }
+    }
+    out[self] = n;
+    need = (count - 1u) + deepest;
+    return (int32_t) self;
 }
 
 // Renumbers nodes and instance records by how often a ray is expected to fetch them
@@ -243,13 +297,14 @@ void order_by_heat(built_accel& out) {
     size_t const node_count = out.nodes.size();
     std::vector<double> heat(node_count, 0.0);
     std::vector<double> instance_heat(out.instances.size(), 0.0);
+    std::vector<char> is_tlas(node_count, 0);
     struct visit {
         int32_t node;
         double heat;
     };
     std::vector<visit> todo;
     // Spreads `h` from `root` down one tree; `on_leaf(code, h)` sees the leaves.
-    auto spread = [&](int32_t root, double h, auto&& on_leaf) {
+    auto spread = [&](int32_t root, double h, bool tlas, auto&& on_leaf) {
         if (root < 0) {
             on_leaf(root, h);
             return;
@@ -259,23 +314,34 @@ void order_by_heat(built_accel& out) {
             visit const v = todo.back();
             todo.pop_back();
             heat[(size_t) v.node] += v.heat;
+            is_tlas[(size_t) v.node] = tlas ? 1 : 0;
             wide_node const& n = out.nodes[(size_t) v.node];
-            float const whole = union_area(n);
-            for (int child = 0; child < 2; ++child) {
+            box3 all;
+            for (int c = 0; c < 4; ++c) {
+                if (n.child[c] != kNoChild) {
+                    all.grow(child_box(n, c));
+                }
+            }
+            float const whole = all.half_area();
+            for (int c = 0; c < 4; ++c) {
+                int32_t const ref = n.child[c];
+                if (ref == kNoChild) {
+                    continue;
+                }
                 double share = v.heat;
                 if (whole > 0.0f) {
-                    share = v.heat * std::min(1.0, (double) child_area(n, child) / (double) whole);
+                    share = v.heat *
+                            std::min(1.0, (double) child_box(n, c).half_area() / (double) whole);
                 }
-                int32_t const c = child == 0 ? n.child0 : n.child1;
-                if (c >= 0) {
-                    todo.push_back({c, share});
+                if (ref >= 0) {
+                    todo.push_back({ref, share});
                 } else {
-                    on_leaf(c, share);
+                    on_leaf(ref, share);
                 }
             }
         }
     };
-    spread(out.tlas_root, 1.0, [&](int32_t code, double h) {
+    spread(out.tlas_root, 1.0, true, [&](int32_t code, double h) {
         instance_heat[((uint32_t) ~code) >> 3] += h;
     });
     std::vector<double> root_heat(node_count, 0.0);
@@ -286,7 +352,7 @@ void order_by_heat(built_accel& out) {
     }
     for (size_t r = 0; r < node_count; ++r) {
         if (root_heat[r] > 0.0) {
-            spread((int32_t) r, root_heat[r], [](int32_t, double) {});
+            spread((int32_t) r, root_heat[r], false, [](int32_t, double) {});
         }
     }
 
@@ -306,26 +372,10 @@ void order_by_heat(built_accel& out) {
     std::vector<uint32_t> const node_rank = ranking(heat);
     std::vector<uint32_t> const instance_rank = ranking(instance_heat);
 
-    // TLAS leaves name instance records; find them before the nodes move.
-    std::vector<char> is_tlas(node_count, 0);
-    {
-        std::vector<int32_t> walk;
-        if (out.tlas_root >= 0) {
-            walk.push_back(out.tlas_root);
-        }
-        while (!walk.empty()) {
-            int32_t const v = walk.back();
-            walk.pop_back();
-            is_tlas[(size_t) v] = 1;
-            if (out.nodes[(size_t) v].child0 >= 0) {
-                walk.push_back(out.nodes[(size_t) v].child0);
-            }
-            if (out.nodes[(size_t) v].child1 >= 0) {
-                walk.push_back(out.nodes[(size_t) v].child1);
-            }
-        }
-    }
     auto remap = [&](int32_t ref, bool tlas) -> int32_t {
+        if (ref == kNoChild) {
+            return ref;
+        }
         if (ref >= 0) {
             return (int32_t) node_rank[(size_t) ref];
         }
@@ -337,8 +387,9 @@ void order_by_heat(built_accel& out) {
     std::vector<wide_node> nodes(node_count);
     for (size_t i = 0; i < node_count; ++i) {
         wide_node n = out.nodes[i];
-        n.child0 = remap(n.child0, is_tlas[i] != 0);
-        n.child1 = remap(n.child1, is_tlas[i] != 0);
+        for (int c = 0; c < 4; ++c) {
+            n.child[c] = remap(n.child[c], is_tlas[i] != 0);
+        }
         nodes[node_rank[i]] = n;
     }
     out.nodes.swap(nodes);
@@ -372,6 +423,7 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
     built_accel out;
     out.tris.reserve(sc.triangle_count);
     tree_builder builder;
+    std::vector<bin_node> bin;  // binary trees of the TLAS and of every BLAS
 
     // Object-space bounds of every mesh.
     std::vector<box3> mesh_bounds(sc.mesh_count);
@@ -449,8 +501,8 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
     // least 12 levels (4 * 2^12 triangles balanced); the TLAS gets the rest at most.
     uint32_t const tlas_limit = kStackEntries - 1u - 12u;
     uint32_t deepest_tlas = 0;
-    out.tlas_root = builder.build(out.nodes, prims.data(), sc.instance_count, 1u, 0u, tlas_limit,
-        emit_instance, deepest_tlas);
+    int32_t const tlas_bin_root = builder.build(bin, prims.data(), sc.instance_count, 1u, 0u,
+        tlas_limit, emit_instance, deepest_tlas);
 
     // One BLAS per mesh, shared by its instances.
     uint32_t const blas_limit = kStackEntries - 1u - deepest_tlas;
@@ -494,14 +546,37 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
             leaf_size = 8u;
         }
         uint32_t deepest = 0;
-        mesh_root[m] = builder.build(out.nodes, prims.data(), mesh.triangle_count, leaf_size, 0u,
+        mesh_root[m] = builder.build(bin, prims.data(), mesh.triangle_count, leaf_size, 0u,
             blas_limit, emit, deepest);
         deepest_blas = std::max(deepest_blas, deepest);
     }
-    for (instance_rec& rec : out.instances) {
-        rec.blas_root = mesh_root[(uint32_t) rec.blas_root];
+    // Collapse the binary trees into 4-wide nodes.  A wide walk can have up to three siblings
+    // pending per level; if that does not fit the traversal stack, keep the trees binary
+    // (their depth was bounded above).
+    for (uint32_t arity : {4u, 2u}) {
+        std::vector<wide_node> nodes;
+        uint32_t need_tlas = 0, need_blas = 0;
+        out.tlas_root = collapse(bin, tlas_bin_root, arity, nodes, need_tlas);
+        std::vector<int32_t> wide_root(sc.mesh_count);
+        for (uint32_t m = 0; m < sc.mesh_count; ++m) {
+            uint32_t need = 0;
+            wide_root[m] = collapse(bin, mesh_root[m], arity, nodes, need);
+            need_blas = std::max(need_blas, need);
+        }
+        out.max_stack_bound = need_tlas + 1u + need_blas;
+        if (out.max_stack_bound > kStackEntries && arity > 2u) {
+            continue;
+        }
+        for (instance_rec& rec : out.instances) {
+            rec.blas_root = wide_root[(uint32_t) rec.blas_root];  // held the mesh index so far
+        }
+        out.nodes.swap(nodes);
+        break;
     }
-    out.max_stack_bound = deepest_tlas + 1u + deepest_blas;
+    if (out.max_stack_bound > kStackEntries ||
+        out.max_stack_bound > 3u * (deepest_tlas + deepest_blas) + 1u) {
+        throw std::runtime_error("accel: tree does not fit the traversal stack");
+    }
     order_by_heat(out);
     return out;
 }

@@ -15,19 +15,24 @@ struct texture_dev {
     uint32_t _pad;
 };
 
-// 64-byte node of the rebuilt BVH: both children's boxes live in the parent,
-// so one aligned 64-byte fetch decides the whole step.
-//   child >= 0 : index of an inner node
-//   child <  0 : leaf; ~child = (first << 3) | (count - 1)   (count 1..8)
+// 128-byte node of the rebuilt BVH: up to FOUR children with their boxes (full floats), laid
+// out per plane so that child c is component c of each float4.  The walk runs at the latency
+// of its dependent fetches; seven 16-byte loads issued together cost one latency, like the
+// four of a two-child node, and the walk has two thirds as many steps.
+//   child >= 0            : index of an inner node
+//   child <  0            : leaf; ~child = (first << 3) | (count - 1)   (count 1..8)
+//   child == kNoChild     : unused slot (its box is inverted: never hit)
 // "first" indexes tri_pos (BLAS) or instance records (TLAS).
+constexpr int32_t kNoChild = 0x7FFFFFFE;
+constexpr uint32_t kWideNodeQuads = 8;  // float4s per node (the last one is padding)
+
 struct wide_node {
-    float lo0x, lo0y, lo0z, hi0x;
-    float hi0y, hi0z, lo1x, lo1y;
-    float lo1z, hi1x, hi1y, hi1z;
-    int32_t child0, child1;
-    uint32_t _pad0, _pad1;
+    float lo_x[4], lo_y[4], lo_z[4];
+    float hi_x[4], hi_y[4], hi_z[4];
+    int32_t child[4];
+    uint32_t _pad[4];
 };
-static_assert(sizeof(wide_node) == 64, "wide_node must be one 64-byte line");
+static_assert(sizeof(wide_node) == 128, "wide_node is eight float4");
 
 // Positions-only triangle of the rebuilt BLAS: 48 bytes, three 16-byte loads.
 // w0 carries the triangle's index in the uploaded (reference-ordered) array.

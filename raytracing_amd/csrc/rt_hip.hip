@@ -683,7 +683,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     bool const each = (r.cfg.flags & RT_HIP_FLAG_TIME_KERNELS) != 0;
 
     uint32_t const extend_lds =
-        (w.sc.cached_nodes + w.sc.cached_instances) * 64u +
+        w.sc.cached_nodes * (uint32_t) sizeof(wide_node) + w.sc.cached_instances * 64u +
         (kExtendThreads / 64u) * w.sc.stack_entries * 256u;
     uint32_t const shade_lds = plan_shade_tables(w.sc, kShadeLdsBudget).total;
     auto extend = [&](uint32_t trip, uint32_t chunk_bound) {
@@ -965,7 +965,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             d.cached_instances =
                 (uint32_t) std::min<size_t>(accel.instances.size(), spare / 2u / 64u);
             d.cached_nodes = (uint32_t) std::min<size_t>(accel.nodes.size(),
-                (spare - d.cached_instances * 64u) / 64u);
+                (spare - d.cached_instances * 64u) / sizeof(wide_node));
         }
         r->sc = d;
         r->scene_ready = true;

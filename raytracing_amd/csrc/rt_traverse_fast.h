@@ -2,9 +2,11 @@
 //
 // Layout choices for gfx950 (no ray-tracing hardware, 64-wide waves, one ray
 // per lane):
-//   * 64-byte nodes that carry BOTH children's boxes: one aligned 64-byte
-//     fetch (four dwordx4 loads) decides a whole step, instead of two
-//     dependent 40-byte fetches that straddle cache lines;
+//   * 128-byte nodes that carry the boxes of up to FOUR children: the walk
+//     runs at the latency of its dependent fetches, seven 16-byte loads issued
+//     together cost one latency, and a 4-wide tree has two thirds of the steps
+//     of a binary one (the reference's 40-byte binary nodes need a dependent
+//     fetch per child);
 //   * a positions-only 48-byte triangle stream in leaf order (the reference
 //     fetches 96 bytes, 60 of them normals/uvs, for every tested triangle);
 //   * TLAS and BLAS walked in ONE loop with one stack: entering an instance
@@ -16,8 +18,9 @@
 //     would cost more than the walk itself;
 //   * the traversal stack lives in LDS (stack[entry][lane]: conflict-free for
 //     a wave); the builder bounds the tree depth so it cannot overflow;
-//   * nearer child first by entry distance; the farther child is pushed and
-//     its own children are tested against the then-current t_max when popped.
+//   * children are visited nearest first by entry distance; the others that
+//     were hit are pushed farthest first and tested against the then-current
+//     t_max when popped.
 //
 // The triangle test is the reference's arithmetic unchanged (hit_triangle),
 // applied to the same object-space ray, so t and the barycentrics of a given
@@ -30,11 +33,11 @@
 
 namespace rtd {
 
-// Per-lane LDS stack entries.  The builder bounds the depth of its trees so that
-// TLAS depth + 1 (instance marker) + BLAS depth never exceeds this, which is why
+// Per-lane LDS stack entries.  The builder bounds its trees so that the siblings a walk
+// can have pending (TLAS + instance marker + BLAS) never exceed this, which is why
 // there is no overflow path (a private overflow array would live in scratch
 // memory, and scratch-heavy kernels get fewer resident waves).
-constexpr uint32_t kFastLdsEntries = 32;
+constexpr uint32_t kFastLdsEntries = 40;
 constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
 
 struct fast_stack {
@@ -103,7 +106,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     uint32_t sp = 0;
     auto slot = [&](uint32_t entry) -> uint32_t {
         // never wraps: the builder bounds the depth and upload checks it against the stack
-        return (CACHED ? entry : (entry & (kFastLdsEntries - 1u))) * 64u;
+        return entry * 64u;
     };
     auto push = [&](int32_t v) {
         stk.lds[slot(sp)] = (uint32_t) v;
@@ -132,32 +135,57 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
 
     for (;;) {
         if (cur >= 0) {
-            const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
-            float4 n0, n1, n2, n3;
+            float4 lx, ly, lz, hx, hy, hz, kids;
             if (CACHED && (uint32_t) cur < stk.cached_nodes) {
-                const float4* lp = stk.node_cache + 4u * (uint32_t) cur;
-                n0 = lp[0], n1 = lp[1], n2 = lp[2], n3 = lp[3];
+                const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+                lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
             } else {
-                n0 = np[0], n1 = np[1], n2 = np[2], n3 = np[3];
+                const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+                lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
             }
             if (COUNT) {
                 ++cnt.nodes;
             }
-            float e0, x0, e1, x1;
-            slab_box(slab, n0.x, n0.y, n0.z, n0.w, n1.x, n1.y, t_max, e0, x0);
-            slab_box(slab, n1.z, n1.w, n2.x, n2.y, n2.z, n2.w, t_max, e1, x1);
-            bool const h0 = e0 <= x0;
-            bool const h1 = e1 <= x1;
-            int32_t const c0 = __float_as_int(n3.x);
-            int32_t const c1 = __float_as_int(n3.y);
-            if (h0 && h1) {
-                bool const first0 = e0 <= e1;
-                push(first0 ? c1 : c0);
-                cur = first0 ? c0 : c1;
-                continue;
+            int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y),
+                __float_as_int(kids.z), __float_as_int(kids.w)};
+            float key[4];
+            float const miss = kInfinity * 2.0f;  // beyond any entry distance
+            {
+                float e, x;
+                slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
+                key[0] = e <= x ? e : miss;
+                slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
+                key[1] = e <= x ? e : miss;
+                slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
+                key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
+                slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
+                key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
             }
-            if (h0 || h1) {
-                cur = h0 ? c0 : c1;
+            // nearest first: sort the four (distance, child) pairs, misses go last
+            auto order = [&](int i, int j) {
+                bool const swap = key[j] < key[i];
+                float const ki = swap ? key[j] : key[i];
+                float const kj = swap ? key[i] : key[j];
+                int32_t const ri = swap ? ref[j] : ref[i];
+                int32_t const rj = swap ? ref[i] : ref[j];
+                key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
+            };
+            order(0, 1);
+            order(2, 3);
+            order(0, 2);
+            order(1, 3);
+            order(1, 2);
+            if (key[0] < miss) {
+                if (key[3] < miss) {
+                    push(ref[3]);
+                }
+                if (key[2] < miss) {
+                    push(ref[2]);
+                }
+                if (key[1] < miss) {
+                    push(ref[1]);
+                }
+                cur = ref[0];
                 continue;
             }
         } else if (!in_blas) {

@@ -394,7 +394,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         if (blockIdx.x * (kExtendThreads / 64u) >= total_chunks) {
             return;  // none of this workgroup's waves has a chunk: skip filling the caches
         }
-        uint32_t const node_words = p.sc.cached_nodes * 4u;
+        uint32_t const node_words = p.sc.cached_nodes * kWideNodeQuads;
         uint32_t const instance_words = p.sc.cached_instances * 4u;
         const float4* const nodes = reinterpret_cast<const float4*>(p.sc.wide_nodes);
         const float4* const records = reinterpret_cast<const float4*>(p.sc.wide_instances);
