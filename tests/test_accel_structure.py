@@ -1,0 +1,46 @@
+"""The acceleration structure the HIP library rebuilds at upload (4-wide nodes over a
+binned-SAH tree, hottest nodes first), checked on the host without a GPU by
+bin/validate_accel: nodes form trees, every triangle and instance sits in exactly one leaf,
+every child box contains what is below it, and the traversal-stack bound the kernels rely on
+equals what the deepest walk can have pending."""
+import os
+import subprocess
+
+import pytest
+
+from raytracing_amd import host, scenes
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TOOL = os.path.join(ROOT, "raytracing_amd", "bin", "validate_accel")
+
+
+def run_tool(paths):
+    if not os.path.exists(TOOL):
+        pytest.fail(f"{TOOL} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    out = subprocess.run([TOOL] + paths, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == len(paths) and all(": ok - " in l for l in lines), out.stdout
+    return lines
+
+
+def test_reference_scenes():
+    names = ["cornell_box", "hyperion_rect_light", "mustang_red_reduced"]
+    lines = run_tool([scenes.snapshot_path(n) for n in names])
+    # the stack of the traversal kernels has 40 entries per lane
+    for line in lines:
+        bound = int(line.split("stack bound ")[1].split()[0])
+        assert 1 <= bound <= 40, line
+
+
+def test_generated_scenes(tmp_path):
+    """1 604 instances of one mesh (a deep TLAS over a shared BLAS) and the textured scene."""
+    inst = host.HostScene.from_json(scenes.write_instanced_scene(
+        str(tmp_path / "i"), grid=40, sphere_segments=24, sphere_rings=12,
+        resolution=(320, 180), tile=(64, 36)))
+    tex = host.HostScene.from_json(scenes.write_textured_scene(str(tmp_path / "t")))
+    paths = [str(tmp_path / "inst.rtsnap"), str(tmp_path / "tex.rtsnap")]
+    inst.save_snapshot(paths[0])
+    tex.save_snapshot(paths[1])
+    lines = run_tool(paths)
+    assert "1604 instances" in lines[0]
