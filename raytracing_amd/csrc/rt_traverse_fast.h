@@ -133,62 +133,222 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         return false;
     }
 
+    if constexpr (!CACHED) {
+        // The fused kernels: one step of whatever kind per trip of the loop.  (The descent
+        // loop below measured 20 % slower there: with two waves per SIMD the lanes idling
+        // through other lanes' descents cost more than the shared leaf rounds save.)
+        for (;;) {
+            if (cur >= 0) {
+                float4 lx, ly, lz, hx, hy, hz, kids;
+                if (CACHED && (uint32_t) cur < stk.cached_nodes) {
+                    const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+                    lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
+                } else {
+                    const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+                    lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
+                }
+                if (COUNT) {
+                    ++cnt.nodes;
+                }
+                int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y),
+                    __float_as_int(kids.z), __float_as_int(kids.w)};
+                float key[4];
+                float const miss = kInfinity * 2.0f;  // beyond any entry distance
+                {
+                    float e, x;
+                    slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
+                    key[0] = e <= x ? e : miss;
+                    slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
+                    key[1] = e <= x ? e : miss;
+                    slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
+                    key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
+                    slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
+                    key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
+                }
+                // nearest first: sort the four (distance, child) pairs, misses go last
+                auto order = [&](int i, int j) {
+                    bool const swap = key[j] < key[i];
+                    float const ki = swap ? key[j] : key[i];
+                    float const kj = swap ? key[i] : key[j];
+                    int32_t const ri = swap ? ref[j] : ref[i];
+                    int32_t const rj = swap ? ref[i] : ref[j];
+                    key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
+                };
+                order(0, 1);
+                order(2, 3);
+                order(0, 2);
+                order(1, 3);
+                order(1, 2);
+                if (key[0] < miss) {
+                    if (key[3] < miss) {
+                        push(ref[3]);
+                    }
+                    if (key[2] < miss) {
+                        push(ref[2]);
+                    }
+                    if (key[1] < miss) {
+                        push(ref[1]);
+                    }
+                    cur = ref[0];
+                    continue;
+                }
+            } else if (!in_blas) {
+                // TLAS leaf: exactly one instance.  Enter its BLAS.
+                uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
+                const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+                float4 r0, r1, r2, r3;
+                if (CACHED && rec_index < stk.cached_instances) {
+                    const float4* lp = stk.instance_cache + 4u * rec_index;
+                    r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+                } else {
+                    r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
+                }
+                // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
+                f3 o, d;
+                o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
+                o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
+                o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
+                d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
+                d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
+                d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
+                slab = make_slab_ray(o, d);
+                tr = make_tri_ray(o, d);
+                current_instance = (uint32_t) __float_as_int(r3.y);
+                push(kInstanceMarker);
+                in_blas = true;
+                cur = __float_as_int(r3.x);
+                continue;
+            } else {
+                // BLAS leaf: 1..8 triangles.
+                uint32_t const code = (uint32_t) ~cur;
+                uint32_t const first = code >> 3;
+                uint32_t const count = (code & 7u) + 1u;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+                    float4 const va = tp[0], vb = tp[1], vc = tp[2];
+                    if (COUNT) {
+                        ++cnt.tris;
+                    }
+                    float b0, b1, b2, th;
+                    if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
+                            mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th)) {
+                        if (ANY) {
+                            return true;
+                        }
+                        t_max = th;
+                        found = true;
+                        best.instance = current_instance;
+                        best.triangle = (uint32_t) __float_as_int(va.w);
+                        best.b0 = b0;
+                        best.b1 = b1;
+                        best.b2 = b2;
+                        best.t = th;
+                    }
+                }
+            }
+            // pop the next subtree; leaving an instance restores the world-space ray
+            for (;;) {
+                if (sp == 0) {
+                    return found;
+                }
+                cur = pop();
+                if (cur != kInstanceMarker) {
+                    break;
+                }
+                in_blas = false;
+                slab = world_slab;
+            }
+        }
+    }
+    // "Nothing left" value of `cur`: no leaf code equals it (the builder refuses scenes with
+    // 2^28 triangles or more).
+    constexpr int32_t kDone = (int32_t) 0x80000000u;
+    // Pops the next subtree; leaving an instance restores the world-space ray.
+    auto next_subtree = [&]() {
+        for (;;) {
+            if (sp == 0) {
+                cur = kDone;
+                return;
+            }
+            cur = pop();
+            if (cur != kInstanceMarker) {
+                return;
+            }
+            in_blas = false;
+            slab = world_slab;
+        }
+    };
+    // One inner node: goes to the nearest hit child (pushing the others) or pops.
+    auto node_step = [&]() {
+        float4 lx, ly, lz, hx, hy, hz, kids;
+        if (CACHED && (uint32_t) cur < stk.cached_nodes) {
+            const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+            lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
+        } else {
+            const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+            lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
+        }
+        if (COUNT) {
+            ++cnt.nodes;
+        }
+        int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y), __float_as_int(kids.z),
+            __float_as_int(kids.w)};
+        float key[4];
+        float const miss = kInfinity * 2.0f;  // beyond any entry distance
+        {
+            float e, x;
+            slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
+            key[0] = e <= x ? e : miss;
+            slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
+            key[1] = e <= x ? e : miss;
+            slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
+            key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
+            slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
+            key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
+        }
+        // nearest first: sort the four (distance, child) pairs, misses go last
+        auto order = [&](int i, int j) {
+            bool const swap = key[j] < key[i];
+            float const ki = swap ? key[j] : key[i];
+            float const kj = swap ? key[i] : key[j];
+            int32_t const ri = swap ? ref[j] : ref[i];
+            int32_t const rj = swap ? ref[i] : ref[j];
+            key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
+        };
+        order(0, 1);
+        order(2, 3);
+        order(0, 2);
+        order(1, 3);
+        order(1, 2);
+        if (key[0] < miss) {
+            if (key[3] < miss) {
+                push(ref[3]);
+            }
+            if (key[2] < miss) {
+                push(ref[2]);
+            }
+            if (key[1] < miss) {
+                push(ref[1]);
+            }
+            cur = ref[0];
+        } else {
+            next_subtree();
+        }
+    };
+
     for (;;) {
         if (cur >= 0) {
-            float4 lx, ly, lz, hx, hy, hz, kids;
-            if (CACHED && (uint32_t) cur < stk.cached_nodes) {
-                const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
-                lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
-            } else {
-                const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
-                lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
-            }
-            if (COUNT) {
-                ++cnt.nodes;
-            }
-            int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y),
-                __float_as_int(kids.z), __float_as_int(kids.w)};
-            float key[4];
-            float const miss = kInfinity * 2.0f;  // beyond any entry distance
-            {
-                float e, x;
-                slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
-                key[0] = e <= x ? e : miss;
-                slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
-                key[1] = e <= x ? e : miss;
-                slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
-                key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
-                slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
-                key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
-            }
-            // nearest first: sort the four (distance, child) pairs, misses go last
-            auto order = [&](int i, int j) {
-                bool const swap = key[j] < key[i];
-                float const ki = swap ? key[j] : key[i];
-                float const kj = swap ? key[i] : key[j];
-                int32_t const ri = swap ? ref[j] : ref[i];
-                int32_t const rj = swap ? ref[i] : ref[j];
-                key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
-            };
-            order(0, 1);
-            order(2, 3);
-            order(0, 2);
-            order(1, 3);
-            order(1, 2);
-            if (key[0] < miss) {
-                if (key[3] < miss) {
-                    push(ref[3]);
-                }
-                if (key[2] < miss) {
-                    push(ref[2]);
-                }
-                if (key[1] < miss) {
-                    push(ref[1]);
-                }
-                cur = ref[0];
-                continue;
-            }
-        } else if (!in_blas) {
+            // The pipeline's trace kernel lets every lane descend until it holds a leaf or has
+            // nothing left before any lane enters an instance or tests triangles: lanes then
+            // wait for the other kinds of step once per round, not on every step.
+            do {
+                node_step();
+            } while (cur >= 0);
+        }
+        if (cur == kDone) {
+            return found;
+        }
+        if (!in_blas) {
             // TLAS leaf: exactly one instance.  Enter its BLAS.
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
             const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
@@ -214,46 +374,34 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             in_blas = true;
             cur = __float_as_int(r3.x);
             continue;
-        } else {
-            // BLAS leaf: 1..8 triangles.
-            uint32_t const code = (uint32_t) ~cur;
-            uint32_t const first = code >> 3;
-            uint32_t const count = (code & 7u) + 1u;
-            for (uint32_t k = 0; k < count; ++k) {
-                const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
-                float4 const va = tp[0], vb = tp[1], vc = tp[2];
-                if (COUNT) {
-                    ++cnt.tris;
+        }
+        // BLAS leaf: 1..8 triangles.
+        uint32_t const code = (uint32_t) ~cur;
+        uint32_t const first = code >> 3;
+        uint32_t const count = (code & 7u) + 1u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+            float4 const va = tp[0], vb = tp[1], vc = tp[2];
+            if (COUNT) {
+                ++cnt.tris;
+            }
+            float b0, b1, b2, th;
+            if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z), mk3(vc.x, vc.y, vc.z),
+                    tr, t_max, b0, b1, b2, th)) {
+                if (ANY) {
+                    return true;
                 }
-                float b0, b1, b2, th;
-                if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
-                        mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th)) {
-                    if (ANY) {
-                        return true;
-                    }
-                    t_max = th;
-                    found = true;
-                    best.instance = current_instance;
-                    best.triangle = (uint32_t) __float_as_int(va.w);
-                    best.b0 = b0;
-                    best.b1 = b1;
-                    best.b2 = b2;
-                    best.t = th;
-                }
+                t_max = th;
+                found = true;
+                best.instance = current_instance;
+                best.triangle = (uint32_t) __float_as_int(va.w);
+                best.b0 = b0;
+                best.b1 = b1;
+                best.b2 = b2;
+                best.t = th;
             }
         }
-        // pop the next subtree; leaving an instance restores the world-space ray
-        for (;;) {
-            if (sp == 0) {
-                return found;
-            }
-            cur = pop();
-            if (cur != kInstanceMarker) {
-                break;
-            }
-            in_blas = false;
-            slab = world_slab;
-        }
+        next_subtree();
     }
 }
 
