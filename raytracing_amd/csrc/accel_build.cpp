@@ -233,12 +233,26 @@ box3 child_box(wide_node const& n, int c) {
     return b;
 }
 
+// Height of every binary node: inner nodes on the longest way down to a leaf.
+void fill_heights(std::vector<bin_node> const& bin, std::vector<uint32_t>& height) {
+    height.assign(bin.size(), 0u);
+    // children are built after their parent, so they have larger indices
+    for (size_t i = bin.size(); i-- > 0;) {
+        uint32_t const h0 = bin[i].child0 >= 0 ? height[(size_t) bin[i].child0] : 0u;
+        uint32_t const h1 = bin[i].child1 >= 0 ? height[(size_t) bin[i].child1] : 0u;
+        height[i] = 1u + std::max(h0, h1);
+    }
+}
+
 // Collapses the binary tree under `root` into wide nodes: the children of a wide node are
-// found by repeatedly opening the inner child with the largest surface area, up to `arity`
-// children.  Returns the reference of the collapsed root; `need` = stack entries a walk of
-// this tree can have pending at once (sum over the deepest path of children - 1).
-int32_t collapse(std::vector<bin_node> const& bin, int32_t root, uint32_t arity,
-    std::vector<wide_node>& out, uint32_t& need) {
+// found by repeatedly opening the inner child with the largest surface area, up to four.
+// A walk can have (children - 1) siblings pending per wide node on its way down; `budget`
+// caps the sum along every path (it must be at least the binary height of `root`, which is
+// what a walk of the uncollapsed tree needs): a child is opened only if everything below
+// still fits.  Deep, narrow parts of a tree therefore stay binary, the rest becomes 4-wide.
+// Returns the reference of the collapsed root; `need` = the sum actually reached.
+int32_t collapse(std::vector<bin_node> const& bin, std::vector<uint32_t> const& height,
+    int32_t root, uint32_t budget, std::vector<wide_node>& out, uint32_t& need) {
     if (root < 0) {
         need = 0;
         return root;  // a tree that is a single leaf
@@ -247,15 +261,33 @@ int32_t collapse(std::vector<bin_node> const& bin, int32_t root, uint32_t arity,
         int32_t ref;
         box3 box;
     };
+    auto height_of = [&](int32_t ref) { return ref >= 0 ? height[(size_t) ref] : 0u; };
     pending kids[4];
     uint32_t count = 2;
     kids[0] = {bin[(size_t) root].child0, bin[(size_t) root].b0};
     kids[1] = {bin[(size_t) root].child1, bin[(size_t) root].b1};
-    while (count < arity) {
+    while (count < 4) {
+        // with one more child, everything below must fit into budget - count
+        if (budget < count) {
+            break;
+        }
+        uint32_t const below = budget - count;
         int best = -1;
         float best_area = -1.0f;
         for (uint32_t i = 0; i < count; ++i) {
-            if (kids[i].ref >= 0 && kids[i].box.half_area() > best_area) {
+            if (kids[i].ref < 0 || kids[i].box.half_area() <= best_area) {
+                continue;
+            }
+            bool fits = true;
+            for (uint32_t j = 0; j < count && fits; ++j) {
+                if (j == i) {
+                    bin_node const& open = bin[(size_t) kids[i].ref];
+                    fits = height_of(open.child0) <= below && height_of(open.child1) <= below;
+                } else {
+                    fits = height_of(kids[j].ref) <= below;
+                }
+            }
+            if (fits) {
                 best_area = kids[i].box.half_area();
                 best = (int) i;
             }
@@ -276,7 +308,8 @@ int32_t collapse(std::vector<bin_node> const& bin, int32_t root, uint32_t arity,
             n.lo_x[i] = kids[i].box.lo[0], n.lo_y[i] = kids[i].box.lo[1], n.lo_z[i] = kids[i].box.lo[2];
             n.hi_x[i] = kids[i].box.hi[0], n.hi_y[i] = kids[i].box.hi[1], n.hi_z[i] = kids[i].box.hi[2];
             uint32_t child_need = 0;
-            n.child[i] = collapse(bin, kids[i].ref, arity, out, child_need);
+            n.child[i] =
+                collapse(bin, height, kids[i].ref, budget - (count - 1u), out, child_need);
             deepest = std::max(deepest, child_need);
         } else {
             // inverted box: no ray interval can be non-empty
@@ -550,33 +583,44 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
             blas_limit, emit, deepest);
         deepest_blas = std::max(deepest_blas, deepest);
     }
-    // Collapse the binary trees into 4-wide nodes.  A wide walk can have up to three siblings
-    // pending per level; if that does not fit the traversal stack, keep the trees binary
-    // (their depth was bounded above).
-    for (uint32_t arity : {4u, 2u}) {
-        std::vector<wide_node> nodes;
-        uint32_t need_tlas = 0, need_blas = 0;
-        out.tlas_root = collapse(bin, tlas_bin_root, arity, nodes, need_tlas);
-        std::vector<int32_t> wide_root(sc.mesh_count);
-        for (uint32_t m = 0; m < sc.mesh_count; ++m) {
-            uint32_t need = 0;
-            wide_root[m] = collapse(bin, mesh_root[m], arity, nodes, need);
-            need_blas = std::max(need_blas, need);
-        }
-        out.max_stack_bound = need_tlas + 1u + need_blas;
-        if (out.max_stack_bound > kStackEntries && arity > 2u) {
-            continue;
-        }
-        for (instance_rec& rec : out.instances) {
-            rec.blas_root = wide_root[(uint32_t) rec.blas_root];  // held the mesh index so far
-        }
-        out.nodes.swap(nodes);
-        break;
+    // Collapse the binary trees into (up to) 4-wide nodes.  The traversal stack is shared by
+    // the TLAS walk, the instance marker and the BLAS walk: split it between the two levels in
+    // proportion to their binary heights (which is what each needs at least).
+    std::vector<uint32_t> height;
+    fill_heights(bin, height);
+    auto height_of = [&](int32_t ref) { return ref >= 0 ? height[(size_t) ref] : 0u; };
+    uint32_t const tlas_height = height_of(tlas_bin_root);
+    uint32_t blas_height = 0;
+    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
+        blas_height = std::max(blas_height, height_of(mesh_root[m]));
     }
-    if (out.max_stack_bound > kStackEntries ||
-        out.max_stack_bound > 3u * (deepest_tlas + deepest_blas) + 1u) {
+    uint32_t const room = kStackEntries - 1u;
+    if (tlas_height + blas_height > room) {
         throw std::runtime_error("accel: tree does not fit the traversal stack");
     }
+    uint32_t blas_budget = blas_height;
+    if (tlas_height + blas_height > 0u) {
+        blas_budget = std::max(blas_height,
+            std::min(room - tlas_height, room * blas_height / (tlas_height + blas_height)));
+    }
+    uint32_t need_blas = 0;
+    std::vector<int32_t> wide_root(sc.mesh_count);
+    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
+        uint32_t need = 0;
+        wide_root[m] = collapse(bin, height, mesh_root[m], blas_budget, out.nodes, need);
+        need_blas = std::max(need_blas, need);
+    }
+    uint32_t need_tlas = 0;
+    out.tlas_root = collapse(bin, height, tlas_bin_root, room - need_blas, out.nodes, need_tlas);
+    for (instance_rec& rec : out.instances) {
+        rec.blas_root = wide_root[(uint32_t) rec.blas_root];  // held the mesh index so far
+    }
+    out.max_stack_bound = need_tlas + 1u + need_blas;
+    if (out.max_stack_bound > kStackEntries) {
+        throw std::runtime_error("accel: tree does not fit the traversal stack");
+    }
+    (void) deepest_tlas;
+    (void) deepest_blas;
     order_by_heat(out);
     return out;
 }
