@@ -48,7 +48,9 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--max-depth", type=int, default=7)
-    ap.add_argument("--spp-per-step", type=int, default=16)
+    ap.add_argument("--spp-per-step", type=int, default=64,
+                    help="passes per render call = one batch of the pipeline (59 M paths, 8.3 GB of "
+                         "path state at 1280x720); 16 per call is 14 %% slower per sample")
     ap.add_argument("--accel", choices=["rebuilt", "reference"], default="rebuilt")
     ap.add_argument("--pipeline", choices=["wavefront", "fused"], default="wavefront",
                     help="trace/shade kernels per bounce (default) or the single fused kernel")

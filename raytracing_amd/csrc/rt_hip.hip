@@ -569,8 +569,10 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
     }
 }
 
-// Paths in flight per batch of the wavefront pipeline: 2^25 paths = 4.6 GB of state.
-constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 25;
+// Paths in flight per batch of the wavefront pipeline: 2^26 paths = 9.4 GB of state (of 288 GB).
+// Large batches amortise the launch tails: 64 passes of a 1280x720 frame per batch render 1.15x
+// faster per sample than 16.
+constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 26;
 
 void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips) {
     if (r.wf_extend_grid == 0) {

@@ -81,9 +81,9 @@ def test_shallow_depths(cornell):
 
 
 def test_batches_of_passes(hyperion):
-    """1280x720 x 40 passes = 36.9 M paths: more than one batch of 2^25 paths.  One call must
+    """1280x720 x 80 passes = 73.7 M paths: more than one batch of 2^26 paths.  One call must
     equal the same passes given in two calls (which also splits the batches elsewhere)."""
-    w, h, md, tile, spp = 1280, 720, 3, (128, 72), 40
+    w, h, md, tile, spp = 1280, 720, 3, (128, 72), 80
     r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
     try:
         r.upload_scene(hyperion.desc)
@@ -95,8 +95,8 @@ def test_batches_of_passes(hyperion):
         assert passes == spp
         assert r.stats(reset=True)["samples"] == w * h * spp
         r.clear()
-        r.render(cam, 0, 17)
-        r.render(cam, 17, 23)
+        r.render(cam, 0, 37)
+        r.render(cam, 37, 43)
         two, _ = r.read_accum()
         assert same(one, two)
     finally:
