@@ -54,6 +54,9 @@ def parse_args():
     ap.add_argument("--accel", choices=["rebuilt", "reference"], default="rebuilt")
     ap.add_argument("--pipeline", choices=["wavefront", "fused"], default="wavefront",
                     help="trace/shade kernels per bounce (default) or the single fused kernel")
+    ap.add_argument("--binning", choices=["auto", "on", "off"], default="auto",
+                    help="regroup the ray queues before each trace launch: decided per scene by "
+                         "the library during warm-up (auto), or forced")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target duration of the CPU baseline sample")
@@ -130,6 +133,7 @@ def main():
     cam = sc.camera(args.width, args.height)
     accel = hip.ACCEL_REBUILT if args.accel == "rebuilt" else hip.ACCEL_REFERENCE
     flags = hip.FLAG_FUSED if args.pipeline == "fused" else hip.FLAG_TIME_KERNELS
+    flags |= {"auto": 0, "on": hip.FLAG_BIN_RAYS, "off": hip.FLAG_NO_BIN_RAYS}[args.binning]
     r = hip.HipRenderer(args.width, args.height, args.max_depth, tile, device=local_rank,
                         accel=accel, flags=flags)
     r.upload_scene(sc.desc)
@@ -204,7 +208,10 @@ def main():
                 traced = sum(per_bounce[:per_call]) * launches  # every call traces the same counts +- noise
                 per_ray = k["nodes_per_ray"] * NODE_BYTES + k["tris_per_ray"] * TRI_BYTES
                 bytes_l = traced * per_ray / max(n, 1)
-                extra = {"rays_per_bounce_last_call": per_bounce,
+                binning_state, probe_ns = r.ray_binning()
+                extra = {"ray_binning": ["undecided", "off", "on"][binning_state],
+                         "ray_binning_probe_ns_per_ray": probe_ns,
+                         "rays_per_bounce_last_call": per_bounce,
                          "trace_launches_per_call": per_call,
                          "render_call_avg_ms": kernel_ms, "render_calls": launches,
                          "shade_kernel_avg_ms": shade_ms, "shade_launches": shade_n,

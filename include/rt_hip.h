@@ -49,7 +49,21 @@ enum {
     RT_HIP_FLAG_FUSED = 2u,
     /* Also time the pipeline's trace and shade launches one by one (two HIP events per
      * launch); see rt_hip_kernel_time_of. */
-    RT_HIP_FLAG_TIME_KERNELS = 4u
+    RT_HIP_FLAG_TIME_KERNELS = 4u,
+    /* Ray binning in the pipeline: before each bounce's trace launch, regroup the ray queues
+     * so that a wave traces rays that start in the same part of the scene and point the same
+     * way.  Pays off on scenes whose incoherent rays are expensive to trace (interiors), costs
+     * a few percent on scenes whose rays are cheap; images are bit-identical either way.
+     * Default (neither flag): decided per uploaded scene from the measured cost of tracing
+     * its third bounce, see rt_hip_ray_binning.  The flags force it on or off. */
+    RT_HIP_FLAG_BIN_RAYS = 8u,
+    RT_HIP_FLAG_NO_BIN_RAYS = 16u
+};
+
+enum {
+    RT_HIP_BINNING_UNDECIDED = 0, /* no render call large enough to measure yet */
+    RT_HIP_BINNING_OFF = 1,
+    RT_HIP_BINNING_ON = 2
 };
 
 enum {
@@ -156,6 +170,12 @@ int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
  * alive in bounce `trip` (counts[0]) and how many closest-hit (counts[1]) and occlusion
  * (counts[2]) rays it traced.  Synchronises the device.  No counterpart in the reference. */
 int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts);
+
+/* Diagnostics of the pipeline: whether ray binning is in use for the uploaded scene
+ * (RT_HIP_BINNING_*) and, when it was decided by measurement, the measured cost of tracing
+ * one ray of the third bounce without binning, in nanoseconds of whole-GPU time (0 when
+ * forced by a flag or not yet measured).  No counterpart in the reference. */
+int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per_ray);
 
 /* Replaces megakernel_raytracer_destroy (:793-813). */
 int rt_hip_destroy(rt_hip_renderer* r);

@@ -38,6 +38,8 @@ def lib():
                                     C.POINTER(Params), fp, C.POINTER(T.Stats)]
         l.oracle_primary_ids.argtypes = [C.POINTER(T.SceneDesc), C.POINTER(T.Camera),
                                          C.POINTER(Params), u32p, u32p, fp, fp]
+        l.oracle_set_ulp_noise.argtypes = [C.c_int]
+        l.oracle_set_ulp_noise.restype = None
         l.oracle_rand01_sequence.argtypes = [C.c_uint32, C.c_uint32, fp, u32p]
         l.oracle_rand01_sequence.restype = None
         l.oracle_hash_combine.argtypes = [C.c_uint32, C.c_uint32]
@@ -114,6 +116,18 @@ def primary_ids(desc, camera, width, height, tile, seeds, threads=0):
     if rc != 0:
         raise RuntimeError("oracle_primary_ids: invalid arguments")
     return inst, tri, t, bary
+
+
+class ulp_noise:
+    """Context manager: renders inside it see transcendental results perturbed in the last bit
+    (oracle.h: oracle_set_ulp_noise), for measuring how sensitive an image is to the math
+    library."""
+
+    def __enter__(self):
+        lib().oracle_set_ulp_noise(1)
+
+    def __exit__(self, *exc):
+        lib().oracle_set_ulp_noise(0)
 
 
 def rand01_sequence(seed, n):

@@ -41,6 +41,32 @@
 #define RT_INFINITY ((float) (1.0 / 0.00000000000001))
 #define EPSILON 0.0001f
 
+/* Sensitivity probe (oracle_set_ulp_noise).  GLSL and libm both allow the transcendental
+ * functions an error of a unit in the last place or more, and the device library's results
+ * differ from glibc's in the last bit for a few percent of the arguments.  With the probe on,
+ * one call in eight (chosen by a hash of the exact result, so runs are reproducible) returns
+ * the neighbouring float instead: an equally valid libm.  Comparing a render with and without
+ * it shows how much of an image such differences can move; the tolerances of the GPU parity
+ * tests are set against that.  Off by default; never on in a golden or baseline run. */
+static int g_ulp_noise = 0;
+void oracle_set_ulp_noise(int on) { g_ulp_noise = on; }
+static inline float last_bit_noise(float exact) {
+    if (!g_ulp_noise || !(fabsf(exact) < RT_INFINITY)) return exact;
+    uint32_t bits;
+    memcpy(&bits, &exact, 4);
+    uint32_t const h = (bits * 2654435761u) >> 28;
+    if (h == 0) return nextafterf(exact, RT_INFINITY);
+    if (h == 1) return nextafterf(exact, -RT_INFINITY);
+    return exact;
+}
+/* a function-like macro is not expanded inside its own replacement, so these call libm */
+#define sinf(x) last_bit_noise(sinf(x))
+#define cosf(x) last_bit_noise(cosf(x))
+#define acosf(x) last_bit_noise(acosf(x))
+#define atan2f(y, x) last_bit_noise(atan2f(y, x))
+#define powf(x, y) last_bit_noise(powf(x, y))
+#define logf(x) last_bit_noise(logf(x))
+
 #define STACK_CAPACITY 1024
 #define CANDIDATE_CAPACITY 65536
 

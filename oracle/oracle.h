@@ -55,6 +55,11 @@ int oracle_primary_ids(const rt_scene_desc* scene, const rt_camera* camera,
     const oracle_params* params, uint32_t* instance_ids, uint32_t* triangle_ids,
     float* hit_t, float* bary);
 
+/* Sensitivity probe: while on, one transcendental result in eight (sin, cos, acos, atan2, pow,
+ * log) is replaced by a neighbouring float, as a different conforming math library might
+ * return.  Process-wide; not for golden or baseline runs. */
+void oracle_set_ulp_noise(int on);
+
 /* --- function-level probes for known-answer tests --- */
 
 /* random.glsl:4-24.  Starting from `seed`, writes n rand_01() values and the

@@ -83,6 +83,16 @@ struct wavefront_params {
     uint32_t* chunk_counts;  // per 64 raw slots: live | closest << 8 | shadow << 16
     uint32_t* tile_sums;     // per 1024 chunks: 3 words, sums and then offsets of the tile
     uint32_t* control;       // [trip][kCtlWords]
+    // ray binning (sort_rays != 0): the queues regrouped by direction octant and origin cell,
+    // with the rays copied next to them so that the trace launch reads them in queue order
+    uint32_t sort_rays;
+    float sort_lo[3], sort_scale[3];  // cell = (origin - lo) * scale, clamped
+    uint32_t* binned_closest;         // pids
+    uint32_t* binned_shadow;
+    uint16_t* bin_keys_closest;       // [queue position before binning]
+    uint16_t* bin_keys_shadow;
+    uint32_t* bin_hist;               // [kind][workgroup][bin]: counts, then offsets in the bin
+    uint32_t* bin_total;              // [kind][bin]: sizes, then bases of the bins
     unsigned long long* wave_stats;  // [wave][kStatWords]
     unsigned long long* counters;    // closest / occlusion ray totals (one add per launch)
     // frame
@@ -363,6 +373,171 @@ __global__ void __launch_bounds__(kTileThreads) wf_scatter_kernel(wavefront_para
     }
 }
 
+// Ray binning.  After a diffuse bounce the rays of neighbouring pixels point anywhere; a wave
+// tracing 64 of them walks 64 different parts of the tree and most of its lanes idle at any
+// one step.  Regrouping a trip's queue so that a chunk of 64 holds rays that start in the same
+// cell of a coarse grid over the scene and point into the same octant makes a wave's rays
+// visit the same nodes again.  One counting sort per queue and trip: every
+// workgroup histograms its contiguous share of the queue in LDS (count), two small launches
+// turn the [workgroup][bin] counts into offsets (columns, bases), and every workgroup walks its
+// share again
+// and writes each pid to the next free place of its bin (place).  Within a bin the
+// order is that of the shares, i.e. still roughly pid order.  Which lane traces which ray has
+// no influence on any result.
+constexpr uint32_t kBinCellsLog2 = 3;                                    // 8 x 8 x 8 cells
+constexpr uint32_t kBinCount = 32u << (3u * kBinCellsLog2);              // x 24 directions
+constexpr uint32_t kBinThreads = 1024;
+
+RT_DEV uint32_t ray_bin(wavefront_params const& p, float4 o, float4 d) {
+    float const top = (float) ((1u << kBinCellsLog2) - 1u);
+    // fmaxf(NaN, 0) = 0: a ray with a NaN origin lands in cell 0
+    uint32_t const cx = (uint32_t) fminf(fmaxf((o.x - p.sort_lo[0]) * p.sort_scale[0], 0.0f), top);
+    uint32_t const cy = (uint32_t) fminf(fmaxf((o.y - p.sort_lo[1]) * p.sort_scale[1], 0.0f), top);
+    uint32_t const cz = (uint32_t) fminf(fmaxf((o.z - p.sort_lo[2]) * p.sort_scale[2], 0.0f), top);
+    uint32_t const cell = cx | (cy << kBinCellsLog2) | (cz << (2u * kBinCellsLog2));
+    // direction: octant and dominant axis (24 classes, numbered 0..31)
+    uint32_t const octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
+    float const ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    uint32_t const major = ax >= ay ? (ax >= az ? 0u : 2u) : (ay >= az ? 1u : 2u);
+    return (((major << 3) | octant) << (3u * kBinCellsLog2)) | cell;  // < kBinCount
+}
+
+// The share of workgroup `g` of `groups` in a queue of n entries: [first, last), whole chunks.
+RT_DEV void bin_share(uint32_t n, uint32_t g, uint32_t groups, uint32_t& first, uint32_t& last) {
+    uint32_t const per_group = (((n + groups - 1u) / groups) + 63u) & ~63u;
+    first = min(n, g * per_group);
+    last = min(n, first + per_group);
+}
+
+// grid (groups, 2): y = 0 closest-hit queue, y = 1 occlusion queue
+__global__ void __launch_bounds__(kBinThreads) wf_bin_count_kernel(wavefront_params const p,
+    uint32_t trip) {
+    __shared__ uint32_t hist[kBinCount];
+    uint32_t const kind = blockIdx.y;
+    uint32_t const n = p.control[trip * kCtlWords + (kind ? kCtlShadow : kCtlClosest)];
+    if (n == 0u) {
+        return;  // the scan and place launches of this queue return as well
+    }
+    const uint32_t* const queue = kind ? p.q_shadow : p.q_closest;
+    const float4* const src_o = kind ? p.sh_o : p.ray_o;
+    const float4* const src_d = kind ? p.sh_d : p.ray_d;
+    for (uint32_t b = threadIdx.x; b < kBinCount; b += kBinThreads) {
+        hist[b] = 0u;
+    }
+    __syncthreads();
+    uint32_t first, last;
+    bin_share(n, blockIdx.x, gridDim.x, first, last);
+    uint16_t* const keys = kind ? p.bin_keys_shadow : p.bin_keys_closest;
+    for (uint32_t i = first + threadIdx.x; i < last; i += kBinThreads) {
+        uint32_t const pid = queue[i];
+        uint32_t const bin = ray_bin(p, src_o[pid], src_d[pid]);
+        keys[i] = (uint16_t) bin;
+        atomicAdd(&hist[bin], 1u);
+    }
+    __syncthreads();
+    uint32_t* const out = p.bin_hist + ((size_t) kind * gridDim.x + blockIdx.x) * kBinCount;
+    for (uint32_t b = threadIdx.x; b < kBinCount; b += kBinThreads) {
+        out[b] = hist[b];
+    }
+}
+
+// grid (kBinCount / kBinColumnThreads, 2): one thread per bin walks the bin's column of
+// per-workgroup counts (neighbouring threads read neighbouring words), turns it into offsets
+// within the bin and leaves the bin's size in bin_total.
+constexpr uint32_t kBinColumnThreads = 256;
+__global__ void __launch_bounds__(kBinColumnThreads) wf_bin_columns_kernel(wavefront_params const p,
+    uint32_t trip, uint32_t groups) {
+    uint32_t const kind = blockIdx.y;
+    uint32_t const n = p.control[trip * kCtlWords + (kind ? kCtlShadow : kCtlClosest)];
+    uint32_t const bin = blockIdx.x * kBinColumnThreads + threadIdx.x;
+    if (n == 0u || bin >= kBinCount) {
+        return;
+    }
+    uint32_t* const column = p.bin_hist + (size_t) kind * groups * kBinCount + bin;
+    uint32_t running = 0;
+    uint32_t g = 0;
+    for (; g + 8u <= groups; g += 8u) {
+        uint32_t c[8];
+        for (uint32_t k = 0; k < 8u; ++k) {
+            c[k] = column[(size_t) (g + k) * kBinCount];
+        }
+        for (uint32_t k = 0; k < 8u; ++k) {
+            column[(size_t) (g + k) * kBinCount] = running;
+            running += c[k];
+        }
+    }
+    for (; g < groups; ++g) {
+        uint32_t const c = column[(size_t) g * kBinCount];
+        column[(size_t) g * kBinCount] = running;
+        running += c;
+    }
+    p.bin_total[kind * kBinCount + bin] = running;
+}
+
+// grid (2): exclusive scan of one queue's bin sizes, in place (they become the bins' bases).
+__global__ void __launch_bounds__(kBinThreads) wf_bin_bases_kernel(wavefront_params const p,
+    uint32_t trip) {
+    __shared__ uint32_t scratch[kBinThreads];
+    uint32_t const kind = blockIdx.x;
+    uint32_t const n = p.control[trip * kCtlWords + (kind ? kCtlShadow : kCtlClosest)];
+    if (n == 0u) {
+        return;
+    }
+    uint32_t* const totals = p.bin_total + kind * kBinCount;
+    constexpr uint32_t kPerThread = (kBinCount + kBinThreads - 1u) / kBinThreads;
+    uint32_t const first = threadIdx.x * kPerThread;
+    uint32_t own[kPerThread];
+    uint32_t sum = 0;
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        own[k] = first + k < kBinCount ? totals[first + k] : 0u;
+        sum += own[k];
+    }
+    uint32_t const t = threadIdx.x;
+    scratch[t] = sum;
+    __syncthreads();
+    for (uint32_t step = 1; step < kBinThreads; step <<= 1) {
+        uint32_t const add = t >= step ? scratch[t - step] : 0u;
+        __syncthreads();
+        scratch[t] += add;
+        __syncthreads();
+    }
+    uint32_t run = scratch[t] - sum;
+    for (uint32_t k = 0; k < kPerThread; ++k) {
+        if (first + k < kBinCount) {
+            totals[first + k] = run;
+        }
+        run += own[k];
+    }
+}
+
+// grid (groups, 2), the same shares as the count launch
+__global__ void __launch_bounds__(kBinThreads) wf_bin_place_kernel(wavefront_params const p,
+    uint32_t trip) {
+    __shared__ uint32_t cursor[kBinCount];
+    uint32_t const kind = blockIdx.y;
+    uint32_t const n = p.control[trip * kCtlWords + (kind ? kCtlShadow : kCtlClosest)];
+    if (n == 0u) {
+        return;
+    }
+    const uint32_t* const queue = kind ? p.q_shadow : p.q_closest;
+    const uint16_t* const keys = kind ? p.bin_keys_shadow : p.bin_keys_closest;
+    uint32_t* const out_queue = kind ? p.binned_shadow : p.binned_closest;
+    const uint32_t* const offsets = p.bin_hist + ((size_t) kind * gridDim.x + blockIdx.x) * kBinCount;
+    const uint32_t* const bases = p.bin_total + kind * kBinCount;
+    for (uint32_t b = threadIdx.x; b < kBinCount; b += kBinThreads) {
+        cursor[b] = bases[b] + offsets[b];
+    }
+    __syncthreads();
+    uint32_t first, last;
+    bin_share(n, blockIdx.x, gridDim.x, first, last);
+    for (uint32_t i = first + threadIdx.x; i < last; i += kBinThreads) {
+        uint32_t const place = atomicAdd(&cursor[keys[i]], 1u);
+        if (place < n) {  // always: the counts and the places come from the same keys
+            out_queue[place] = queue[i];
+        }
+    }
+}
+
 // Traces every ray of trip `trip`: chunks [0, closest_chunks) hold closest-hit rays, the
 // rest occlusion rays, so a wave never mixes the two kinds.  (A variant in which a lane that
 // finishes its ray takes the next one from the queue, instead of waiting for the slowest
@@ -387,8 +562,9 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
     uint32_t const n_shadow = FIRST ? 0u : ctl[kCtlShadow];
     uint32_t const closest_chunks = (n_closest + 63u) / 64u;
     uint32_t const total_chunks = closest_chunks + (n_shadow + 63u) / 64u;
-    const uint32_t* const q_closest = p.q_closest;
-    const uint32_t* const q_shadow = p.q_shadow;
+    bool const binned = !FIRST && p.sort_rays != 0u;
+    const uint32_t* const q_closest = binned ? p.binned_closest : p.q_closest;
+    const uint32_t* const q_shadow = binned ? p.binned_shadow : p.q_shadow;
     fast_stack stk{};
     if (ACCEL == RT_HIP_ACCEL_REBUILT) {
         if (blockIdx.x * (kExtendThreads / 64u) >= total_chunks) {

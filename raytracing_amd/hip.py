@@ -19,6 +19,9 @@ ACCEL_REBUILT = 1
 FLAG_COUNT_NODES = 1
 FLAG_FUSED = 2
 FLAG_TIME_KERNELS = 4
+FLAG_BIN_RAYS = 8
+FLAG_NO_BIN_RAYS = 16
+BINNING_UNDECIDED, BINNING_OFF, BINNING_ON = 0, 1, 2
 KERNEL_RENDER, KERNEL_EXTEND, KERNEL_SHADE = 0, 1, 2
 MISS = 0xFFFFFFFF
 
@@ -27,7 +30,8 @@ EXPORTS = [
     "rt_hip_render", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes",
-    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts", "rt_hip_destroy", "rt_hip_last_error",
+    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
+    "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
 
@@ -166,6 +170,13 @@ class HipRenderer:
         n = C.c_uint32()
         _check(lib().rt_hip_kernel_time_of(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def ray_binning(self):
+        """(BINNING_* state for the uploaded scene, measured ns per third-bounce ray or 0.0)."""
+        state = C.c_uint32()
+        ns = C.c_double()
+        _check(lib().rt_hip_ray_binning(self._h, C.byref(state), C.byref(ns)))
+        return state.value, ns.value
 
     def trip_counts(self, trip):
         """(live paths, closest-hit rays, occlusion rays) of bounce `trip` in the last batch."""

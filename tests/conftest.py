@@ -54,6 +54,22 @@ def mustang():
 
 
 @pytest.fixture(scope="session")
+def staircase():
+    """assets/staircase.json without the one primitive whose mesh does not ship
+    (tools/make_fixtures.py: reduced_staircase): ten 1024x1024 albedo textures."""
+    from raytracing_amd import scenes
+    return scenes.load_snapshot("staircase_reduced")
+
+
+@pytest.fixture(scope="session")
+def teapot():
+    """assets/teapot.json with a sphere standing in for the two teapot meshes that do not ship
+    and a substitute environment map (tools/make_fixtures.py: teapot_standin)."""
+    from raytracing_amd import scenes
+    return scenes.load_snapshot("teapot_standin")
+
+
+@pytest.fixture(scope="session")
 def textured(tmp_path_factory):
     from raytracing_amd import host, scenes
     d = tmp_path_factory.mktemp("textured")

@@ -25,7 +25,8 @@ def run_tool(paths):
 
 
 def test_reference_scenes():
-    names = ["cornell_box", "hyperion_rect_light", "mustang_red_reduced"]
+    names = ["cornell_box", "hyperion_rect_light", "mustang_red_reduced", "staircase_reduced",
+             "teapot_standin"]
     lines = run_tool([scenes.snapshot_path(n) for n in names])
     # the stack of the traversal kernels has 40 entries per lane
     for line in lines:

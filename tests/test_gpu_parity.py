@@ -8,7 +8,16 @@ Bars:
     between libm and the device library and flips a branch;
   * images (float32): per value |gpu - oracle| <= 1e-3 * |oracle| + 1e-4 for all but a
     fraction 2e-3 of the values (a flipped branch changes a whole path), and a relative
-    RMSE over the image <= 2e-3.
+    RMSE over the image <= 2e-3;
+  * scenes whose paths amplify last-bit differences: the same two measures may reach 3x what
+    the oracle itself shows when one in eight of its sin/cos/acos/atan2/pow/log results is
+    moved to the neighbouring float (oracle.ulp_noise), i.e. the GPU must be as close to the
+    oracle as another conforming math library would be.  Two scenes need this.  The staircase:
+    seven bounces between near-mirror wood and metal (its depth-1 image is still held to the
+    fixed bars).  The teapot file: its floor is one 2000-unit quad, and a ray leaving it starts
+    1e-4 along its own direction (megakernel_raytracer.comp:562), which is less than the
+    rounding error of the triangle test against vertices 1000 units away - whether a grazing
+    ray hits the floor it just left is decided in the last bits, in the oracle as on the GPU.
 """
 import os
 
@@ -24,6 +33,9 @@ from conftest import GOLDEN
 pytestmark = pytest.mark.gpu
 
 ACCELS = [hip.ACCEL_REFERENCE, hip.ACCEL_REBUILT]
+SCENES = {"cornell_box": "cornell", "hyperion_rect_light": "hyperion",
+          "mustang_red_reduced": "mustang", "staircase_reduced": "staircase",
+          "teapot_standin": "teapot"}
 REL_TOL, ABS_TOL, BAD_FRACTION, REL_RMSE = 1e-3, 1e-4, 2e-3, 2e-3
 
 
@@ -33,7 +45,17 @@ def make_renderer(sc, w, h, md, tile, accel, flags=0):
     return r
 
 
-def assert_image_close(got, want, what=""):
+def image_distance(got, want):
+    err = np.abs(got[..., :3] - want[..., :3])
+    tol = REL_TOL * np.abs(want[..., :3]) + ABS_TOL
+    bad = float((err > tol).mean())
+    rmse = float(np.sqrt((err ** 2).mean()) / (np.sqrt((want[..., :3] ** 2).mean()) + 1e-12))
+    return bad, rmse
+
+
+def assert_image_close(got, want, what="", sensitivity=None):
+    """sensitivity: the oracle's own image under last-bit noise in the math library; when given,
+    the bars are raised to 3x its distance from `want` if that is above the fixed bars."""
     # NaN radiance is a property of the shader (an edge-on light sample has pdf = inf, and
     # power_heuristic(inf, x) is NaN): it must appear in the
     # same pixels on both sides; everything else must be finite and close
@@ -41,12 +63,15 @@ def assert_image_close(got, want, what=""):
     keep = ~(np.isnan(got) | np.isnan(want)).any(axis=2)
     got, want = got[keep], want[keep]
     assert np.isfinite(got).all(), what
-    err = np.abs(got[..., :3] - want[..., :3])
-    tol = REL_TOL * np.abs(want[..., :3]) + ABS_TOL
-    bad = float((err > tol).mean())
-    rmse = float(np.sqrt((err ** 2).mean()) / (np.sqrt((want[..., :3] ** 2).mean()) + 1e-12))
-    assert bad <= BAD_FRACTION, f"{what}: {bad:.5f} of the values outside tolerance"
-    assert rmse <= REL_RMSE, f"{what}: relative RMSE {rmse:.3g}"
+    bad, rmse = image_distance(got, want)
+    bad_bar, rmse_bar = BAD_FRACTION, REL_RMSE
+    if sensitivity is not None:
+        noisy = sensitivity[keep]
+        finite = np.isfinite(noisy).all(axis=1)
+        noise_bad, noise_rmse = image_distance(noisy[finite], want[finite])
+        bad_bar, rmse_bar = max(bad_bar, 3 * noise_bad), max(rmse_bar, 3 * noise_rmse)
+    assert bad <= bad_bar, f"{what}: {bad:.5f} of the values outside tolerance (bar {bad_bar:.5f})"
+    assert rmse <= rmse_bar, f"{what}: relative RMSE {rmse:.3g} (bar {rmse_bar:.3g})"
     assert (got[..., 3] == 1.0).all()
 
 
@@ -98,19 +123,40 @@ def test_primary_ids_mustang(mustang, accel):
 
 
 @pytest.mark.parametrize("accel", ACCELS)
+def test_primary_ids_staircase(staircase, accel):
+    # 19 meshes, 88 k triangles, at the file's own 640x800
+    check_ids(staircase, 640, 800, (64, 80), accel)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_primary_ids_teapot(teapot, accel):
+    check_ids(teapot, 640, 360, (128, 72), accel)
+
+
+@pytest.mark.parametrize("accel", ACCELS)
 def test_primary_ids_instanced_scene_beyond_reference_limits(instanced, accel):
     # 1604 instances: rays cross far more than the shader's 15-entry candidate list
     check_ids(instanced, 320, 180, (64, 36), accel)
 
 
+_noisy = {}
+
+
+def oracle_under_noise(name, sc, w, h, md, tile, seeds):
+    if name not in _noisy:
+        with oracle.ulp_noise():
+            _noisy[name], _ = oracle.render(sc.desc, sc.camera(w, h), w, h, md, tile, seeds)
+    return _noisy[name]
+
+
 @pytest.mark.parametrize("accel", ACCELS)
-@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light", "mustang_red_reduced"])
-def test_golden_fixture(name, accel, cornell, hyperion, mustang):
-    sc = {"cornell_box": cornell, "hyperion_rect_light": hyperion,
-          "mustang_red_reduced": mustang}[name]
+@pytest.mark.parametrize("name", list(SCENES))
+def test_golden_fixture(name, accel, request):
+    sc = request.getfixturevalue(SCENES[name])
     z = np.load(os.path.join(GOLDEN, f"oracle_{name}.npz"))
     w, h, tw, th, spp, md = (int(v) for v in z["params"])
     seeds = host.seed_schedule(0, spp, (w // tw) * (h // th))
+    noisy = oracle_under_noise(name, sc, w, h, md, (tw, th), seeds)
     r = make_renderer(sc, w, h, md, (tw, th), accel)
     r.upload_seeds(seeds)
     r.clear()
@@ -119,10 +165,14 @@ def test_golden_fixture(name, accel, cornell, hyperion, mustang):
     st = r.stats()
     r.close()
     assert passes == spp
-    assert_image_close(got, z["accum"], f"{name} accel {accel}")
-    assert abs(st["closest_rays"] - int(z["closest_rays"])) <= 8
+    assert_image_close(got, z["accum"], f"{name} accel {accel}", sensitivity=noisy)
+    # the stand-in sphere has roughness 0: directions sampled from its needle-thin lobe land
+    # within rounding of the horizon often enough that the oracle's own count moves by +-20
+    # of 109 470 when half of its transcendental results are off by one in the last place
+    slack = 32 if name == "teapot_standin" else 8
+    assert abs(st["closest_rays"] - int(z["closest_rays"])) <= slack
     # occlusion rays of light samples that the BSDF then rejects are not traced by the kernel
-    assert abs(st["shadow_rays"] + st["shadow_skipped"] - int(z["shadow_rays"])) <= 8
+    assert abs(st["shadow_rays"] + st["shadow_skipped"] - int(z["shadow_rays"])) <= slack
 
 
 @pytest.mark.parametrize("accel", ACCELS)
@@ -180,6 +230,28 @@ def test_image_parity_instanced(instanced, accel):
     got, _ = r.read_accum()
     r.close()
     assert_image_close(got, want, f"instanced accel {accel}")
+
+
+@pytest.mark.parametrize("accel", ACCELS)
+def test_staircase_depth_one(staircase, accel):
+    """max_depth 1 (direct light through a textured first hit, plus emission seen after one
+    sampled bounce): too short for last-bit differences to grow, so the fixed bars hold and the
+    ray counts are identical."""
+    sc = staircase
+    w, h, tile, spp, md = 320, 400, (64, 80), 4, 1
+    cam = sc.camera(w, h)
+    seeds = host.seed_schedule(0, spp, 25)
+    want, ost = oracle.render(sc.desc, cam, w, h, md, tile, seeds)
+    r = make_renderer(sc, w, h, md, tile, accel)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cam, 0, spp)
+    got, _ = r.read_accum()
+    st = r.stats()
+    r.close()
+    assert_image_close(got, want, f"staircase accel {accel}")
+    assert st["closest_rays"] == ost["closest_rays"]
+    assert st["shadow_rays"] + st["shadow_skipped"] == ost["shadow_rays"]
 
 
 def test_tile_cadence_equals_batched_render(cornell):

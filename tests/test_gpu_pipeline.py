@@ -2,7 +2,8 @@
 memory, LDS-cached traversal, a finishing kernel for the late bounces).  The single fused
 kernel (RT_HIP_FLAG_FUSED, also what rt_hip_render_tile uses) computes every path with the
 same device functions in the same order, so the two must agree bit for bit - images and work
-counters - in both acceleration-structure modes, across batch boundaries and for deep paths."""
+counters - in both acceleration-structure modes, across batch boundaries, for deep paths, and
+with the ray queues regrouped by origin cell and direction (ray binning) or not."""
 import numpy as np
 import pytest
 
@@ -33,26 +34,33 @@ COUNTERS = ["samples", "closest_rays", "shadow_rays", "closest_hits", "shadow_sk
             "nodes_visited", "tris_tested", "max_stack"]
 
 
+BINNING = [hip.FLAG_NO_BIN_RAYS, hip.FLAG_BIN_RAYS]
+
+
+@pytest.mark.parametrize("binning", BINNING)
 @pytest.mark.parametrize("accel", [hip.ACCEL_REFERENCE, hip.ACCEL_REBUILT])
-@pytest.mark.parametrize("scene_name", ["cornell", "hyperion"])
-def test_pipeline_equals_fused_kernel(request, scene_name, accel):
+@pytest.mark.parametrize("scene_name", ["cornell", "hyperion", "staircase"])
+def test_pipeline_equals_fused_kernel(request, scene_name, accel, binning):
+    if accel == hip.ACCEL_REFERENCE and binning == hip.FLAG_BIN_RAYS:
+        pytest.skip("ray binning belongs to the rebuilt acceleration structure's pipeline")
     scene = request.getfixturevalue(scene_name)
     w, h, md, tile, spp = 320, 184, 7, (64, 46), 5   # 184 = 23 * 8; tiles of 64 x 46
     fused = run(scene, w, h, md, tile, spp, accel, hip.FLAG_FUSED | hip.FLAG_COUNT_NODES)
-    piped = run(scene, w, h, md, tile, spp, accel, hip.FLAG_COUNT_NODES)
+    piped = run(scene, w, h, md, tile, spp, accel, hip.FLAG_COUNT_NODES | binning)
     assert fused[1] == piped[1] == spp
     assert same(fused[0], piped[0])
     for k in COUNTERS:
         assert fused[2][k] == piped[2][k], k
 
 
-def test_pipeline_partial_blocks(cornell):
+@pytest.mark.parametrize("binning", BINNING)
+def test_pipeline_partial_blocks(cornell, binning):
     """A rectangle whose sides are not multiples of the 8x8 path blocks: the padding lanes of
     the edge blocks start no path and touch no pixel."""
     w, h, md, tile, spp = 320, 180, 5, (64, 36), 3
     rect = (5, 3, 299, 171)
     fused = run(cornell, w, h, md, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_FUSED, rect)
-    piped = run(cornell, w, h, md, tile, spp, hip.ACCEL_REBUILT, 0, rect)
+    piped = run(cornell, w, h, md, tile, spp, hip.ACCEL_REBUILT, binning, rect)
     assert same(fused[0], piped[0])
     assert piped[2]["samples"] == (299 - 5) * (171 - 3) * spp
     assert (piped[0][:3, :, :3] == 0).all() and (piped[0][:, :5, :3] == 0).all()
@@ -80,11 +88,12 @@ def test_shallow_depths(cornell):
         assert fused[2]["shadow_rays"] == piped[2]["shadow_rays"], md
 
 
-def test_batches_of_passes(hyperion):
+@pytest.mark.parametrize("binning", BINNING)
+def test_batches_of_passes(hyperion, binning):
     """1280x720 x 80 passes = 73.7 M paths: more than one batch of 2^26 paths.  One call must
     equal the same passes given in two calls (which also splits the batches elsewhere)."""
     w, h, md, tile, spp = 1280, 720, 3, (128, 72), 80
-    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=binning)
     try:
         r.upload_scene(hyperion.desc)
         r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
@@ -101,6 +110,49 @@ def test_batches_of_passes(hyperion):
         assert same(one, two)
     finally:
         r.close()
+
+
+def test_ray_binning_is_decided_by_measurement(cornell, staircase):
+    """Without a forcing flag the first large render call of a scene runs unbinned and times
+    the trace launch of its third bounce; the next call reads the result.  Tracing an
+    incoherent ray costs about 0.7 ns of GPU time in the staircase interior and 0.1 ns in the
+    Cornell box, against a threshold of 0.4; the switch does not change a bit of the image."""
+    w, h, md, tile, spp = 640, 800, 7, (64, 80), 12
+    outcome = {}
+    for name, scene in (("cornell", cornell), ("staircase", staircase)):
+        r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+        try:
+            r.upload_scene(scene.desc)
+            r.upload_seeds(host.seed_schedule(0, 2 * spp, r.tile_count))
+            cam = scene.camera(w, h)
+            assert r.ray_binning() == (hip.BINNING_UNDECIDED, 0.0)
+            r.clear()
+            r.render(cam, 0, spp)          # measures
+            r.read_accum()                 # (synchronises)
+            r.render(cam, spp, spp)        # runs with the decision
+            auto, passes = r.read_accum()
+            state, ns = r.ray_binning()
+            assert passes == 2 * spp and state != hip.BINNING_UNDECIDED and ns > 0.0
+            outcome[name] = (state, ns)
+            # a new scene is measured anew
+            r.upload_scene(scene.desc)
+            assert r.ray_binning() == (hip.BINNING_UNDECIDED, 0.0)
+        finally:
+            r.close()
+        r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_NO_BIN_RAYS)
+        try:
+            r.upload_scene(scene.desc)
+            r.upload_seeds(host.seed_schedule(0, 2 * spp, r.tile_count))
+            assert r.ray_binning() == (hip.BINNING_OFF, 0.0)
+            r.clear()
+            r.render(scene.camera(w, h), 0, 2 * spp)
+            plain, _ = r.read_accum()
+        finally:
+            r.close()
+        assert same(auto, plain), name
+    assert outcome["staircase"][0] == hip.BINNING_ON, outcome
+    assert outcome["cornell"][0] == hip.BINNING_OFF, outcome
+    assert outcome["staircase"][1] > 2 * outcome["cornell"][1]
 
 
 def test_trip_counts_and_kernel_times(hyperion):

@@ -1,6 +1,7 @@
 """The oracle against its committed fixtures, its own invariants, and - loosely - against the
-one output of the reference itself that exists: the screenshot outputs/hyperion_rect_light.png
-(unknown sample count and seed, window-sized, tonemapped)."""
+only outputs of the reference itself that exist for scenes that can be loaded: the screenshots
+outputs/hyperion_rect_light.png and outputs/staircase.png (unknown sample count and seed,
+window-sized, tonemapped)."""
 import os
 
 import numpy as np
@@ -18,10 +19,14 @@ def load_golden(name):
     return z, w, h, (tw, th), spp, md
 
 
-@pytest.mark.parametrize("name", ["cornell_box", "hyperion_rect_light", "mustang_red_reduced"])
-def test_oracle_reproduces_golden_bit_for_bit(name, cornell, hyperion, mustang):
-    sc = {"cornell_box": cornell, "hyperion_rect_light": hyperion,
-          "mustang_red_reduced": mustang}[name]
+SCENES = {"cornell_box": "cornell", "hyperion_rect_light": "hyperion",
+          "mustang_red_reduced": "mustang", "staircase_reduced": "staircase",
+          "teapot_standin": "teapot"}
+
+
+@pytest.mark.parametrize("name", list(SCENES))
+def test_oracle_reproduces_golden_bit_for_bit(name, request):
+    sc = request.getfixturevalue(SCENES[name])
     z, w, h, tile, spp, md = load_golden(name)
     seeds = host.seed_schedule(0, spp, (w // tile[0]) * (h // tile[1]))
     cam = sc.camera(w, h)
@@ -34,6 +39,26 @@ def test_oracle_reproduces_golden_bit_for_bit(name, cornell, hyperion, mustang):
     assert stats["shadow_rays"] == int(z["shadow_rays"])
     # libm's sin/cos/pow may differ by an ulp between glibc versions; geometry may not
     assert np.allclose(accum, z["accum"], rtol=1e-4, atol=1e-5)
+
+
+def test_sensitivity_to_the_last_bit_of_the_math_library(cornell, staircase):
+    """What the tolerances of the GPU parity tests rest on.  With one transcendental result in
+    eight moved to the neighbouring float, short diffuse paths (Cornell box, depth 3) stay
+    within 1e-3 relative everywhere, while seven bounces between the staircase's near-mirror
+    wood and metal carry the difference up to whole percents in a few values per thousand:
+    there an implementation with another math library cannot be closer than that."""
+    def distance(name, sc):
+        z, w, h, tile, spp, md = load_golden(name)
+        seeds = host.seed_schedule(0, spp, (w // tile[0]) * (h // tile[1]))
+        with oracle.ulp_noise():
+            noisy, _ = oracle.render(sc.desc, sc.camera(w, h), w, h, md, tile, seeds)
+        again, _ = oracle.render(sc.desc, sc.camera(w, h), w, h, md, tile, seeds)
+        assert np.allclose(again, z["accum"], rtol=1e-4, atol=1e-5)   # the probe is off again
+        err = np.abs(noisy[..., :3] - z["accum"][..., :3])
+        return float((err > 1e-3 * np.abs(z["accum"][..., :3]) + 1e-4).mean())
+
+    assert distance("cornell_box", cornell) == 0.0
+    assert 5e-4 < distance("staircase_reduced", staircase) < 2e-2
 
 
 def test_oracle_pass_and_rect_splits_are_exact(cornell):
@@ -109,3 +134,30 @@ def test_oracle_resembles_the_reference_screenshot(hyperion):
     assert abs(a.mean() - b.mean()) < 0.05
     # red floor: red dominates in both
     assert a[..., 0].mean() > 2 * a[..., 1].mean() and b[..., 0].mean() > 2 * b[..., 1].mean()
+
+
+def test_oracle_resembles_the_reference_staircase_screenshot(staircase):
+    """The same loose pin on the textured scene: outputs/staircase.png is a 635x794 capture of
+    the 640x800 render.  The reference rendered all 20 primitives; the brass fittings missing
+    here (chandelier, socket) are a few thin objects and do not show at this scale.  Agreement
+    of the wallpaper / wood / painting colours also checks the PNG decoder, the texture
+    coordinates and the bilinear fetch end to end."""
+    from PIL import Image
+    ref = np.asarray(Image.open(os.path.join(GOLDEN, "ref_staircase_thumb.png")).convert("RGB"),
+                     dtype=np.float32) / 255.0
+    w, h, tile, spp = 160, 200, (32, 40), 24
+    seeds = host.seed_schedule(0, spp, 25)
+    accum, _ = oracle.render(staircase.desc, staircase.camera(w, h), w, h, 7, tile, seeds)
+    mine = tonemap(np.nan_to_num(accum), spp)
+
+    def coarse(img):  # 10x10 box average -> 20 x 16 cells
+        return img.reshape(20, 10, 16, 10, 3).mean(axis=(1, 3))
+
+    a, b = coarse(mine), coarse(ref)
+    corr = np.corrcoef(a.reshape(-1), b.reshape(-1))[0, 1]
+    assert corr > 0.95, corr
+    assert abs(a.mean() - b.mean()) < 0.05
+    # warm wood and a yellow light: red >= green > blue in both, by similar ratios
+    for c in (a, b):
+        assert c[..., 0].mean() > c[..., 1].mean() > 1.3 * c[..., 2].mean()
+    assert abs(a[..., 2].mean() / a[..., 0].mean() - b[..., 2].mean() / b[..., 0].mean()) < 0.1
