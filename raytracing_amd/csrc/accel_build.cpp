@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <limits>
 #include <stdexcept>
 
@@ -60,6 +61,9 @@ constexpr int kBins = 16;
 constexpr uint32_t kStackEntries = 40;  // = kFastLdsEntries of the traversal kernels
 constexpr float kTraversalCost = 1.2f;
 constexpr float kIntersectCost = 1.0f;
+// An instance may be opened when the boxes of the other instances cover its own box at least
+// this many times over, by surface area.
+constexpr float kOpenOverlap = 3.0f;
 
 int32_t encode_leaf(uint32_t first, uint32_t count) {
     return (int32_t) ~((first << 3) | (count - 1u));
@@ -444,9 +448,51 @@ void set_centroid(build_prim& p) {
     }
 }
 
+// World box of an object-space box under an instance's transform: the 8 transformed corners,
+// padded so that rounding cannot cut a hit off.
+box3 world_box(rt_scene_desc const& sc, rt_instance const& inst, box3 const& ob) {
+    box3 wb;
+    for (int corner = 0; corner < 8; ++corner) {
+        float const p[3] = {(corner & 1) ? ob.hi[0] : ob.lo[0], (corner & 2) ? ob.hi[1] : ob.lo[1],
+            (corner & 4) ? ob.hi[2] : ob.lo[2]};
+        float w[3] = {p[0], p[1], p[2]};
+        if (inst.transform >= 0) {
+            rt_mat4 const& m = sc.transforms[inst.transform];
+            for (int r = 0; r < 3; ++r) {
+                w[r] = m.m[0][r] * p[0] + m.m[1][r] * p[1] + m.m[2][r] * p[2] + m.m[3][r];
+            }
+        }
+        wb.grow(w);
+    }
+    for (int a = 0; a < 3; ++a) {
+        float const pad = 1e-5f * (wb.hi[a] - wb.lo[a]) +
+                          4e-7f * std::max(std::fabs(wb.lo[a]), std::fabs(wb.hi[a])) + 1e-30f;
+        wb.lo[a] -= pad;
+        wb.hi[a] += pad;
+    }
+    return wb;
+}
+
+uint32_t ceil_log2(uint32_t v) {
+    uint32_t bits = 0;
+    while ((1u << bits) < v) {
+        ++bits;
+    }
+    return bits;
+}
+
+// One TLAS leaf: an instance, or - when the instance has been opened - one subtree of its
+// mesh's BLAS.
+struct tlas_entry {
+    uint32_t instance;
+    int32_t subtree;  // binary node, or an encoded leaf
+    box3 object_box;
+    box3 world;
+};
+
 }  // namespace
 
-built_accel build_wide_accel(rt_scene_desc const& sc) {
+built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
     if (sc.instance_count == 0 || sc.mesh_count == 0 || sc.triangle_count == 0) {
         throw std::runtime_error("accel: empty scene");
     }
@@ -456,7 +502,7 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
     built_accel out;
     out.tris.reserve(sc.triangle_count);
     tree_builder builder;
-    std::vector<bin_node> bin;  // binary trees of the TLAS and of every BLAS
+    std::vector<bin_node> bin;  // binary trees of every BLAS and of the TLAS
 
     // Object-space bounds of every mesh.
     std::vector<box3> mesh_bounds(sc.mesh_count);
@@ -473,74 +519,26 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
             mesh_bounds[m].grow(tri.c.position_texu);
         }
     }
-
-    // TLAS first (its depth decides how deep the BLASes may be): world boxes of the
-    // instances = 8 transformed corners of the mesh box, padded so rounding cannot cut a
-    // hit off.
-    std::vector<build_prim> prims(sc.instance_count);
     for (uint32_t i = 0; i < sc.instance_count; ++i) {
         rt_instance const& inst = sc.instances[i];
         if (inst.mesh >= sc.mesh_count ||
             (inst.transform >= 0 && (uint32_t) inst.transform >= sc.transform_count)) {
             throw std::runtime_error("accel: instance refers to a missing mesh or transform");
         }
-        box3 const& mb = mesh_bounds[inst.mesh];
-        box3 wb;
-        for (int corner = 0; corner < 8; ++corner) {
-            float const p[3] = {(corner & 1) ? mb.hi[0] : mb.lo[0],
-                (corner & 2) ? mb.hi[1] : mb.lo[1], (corner & 4) ? mb.hi[2] : mb.lo[2]};
-            float w[3] = {p[0], p[1], p[2]};
-            if (inst.transform >= 0) {
-                rt_mat4 const& m = sc.transforms[inst.transform];
-                for (int r = 0; r < 3; ++r) {
-                    w[r] = m.m[0][r] * p[0] + m.m[1][r] * p[1] + m.m[2][r] * p[2] + m.m[3][r];
-                }
-            }
-            wb.grow(w);
-        }
-        for (int a = 0; a < 3; ++a) {
-            float const pad = 1e-5f * (wb.hi[a] - wb.lo[a]) +
-                              4e-7f * std::max(std::fabs(wb.lo[a]), std::fabs(wb.hi[a])) + 1e-30f;
-            wb.lo[a] -= pad;
-            wb.hi[a] += pad;
-        }
-        prims[i].bounds = wb;
-        set_centroid(prims[i]);
-        prims[i].id = i;
     }
-    auto emit_instance = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
-        (void) count;  // TLAS leaves hold exactly one instance
-        uint32_t const first = (uint32_t) out.instances.size();
-        rt_instance const& inst = sc.instances[leaf[0].id];
-        instance_rec rec{};
-        if (inst.transform >= 0) {
-            rt_mat4 const& inv = sc.inverse_transforms[inst.transform];
-            for (int c = 0; c < 4; ++c) {
-                for (int r = 0; r < 3; ++r) {
-                    rec.m[c * 3 + r] = inv.m[c][r];
-                }
-            }
-            rec.has_transform = 1;
-        } else {
-            rec.m[0] = rec.m[4] = rec.m[8] = 1.0f;
-            rec.has_transform = 0;
-        }
-        rec.blas_root = (int32_t) inst.mesh;  // replaced by the mesh's BLAS root below
-        rec.ref_index = leaf[0].id;
-        out.instances.push_back(rec);
-        return first;
-    };
-    // The stack holds TLAS siblings + one marker + BLAS siblings.  Leave the BLASes at
-    // least 12 levels (4 * 2^12 triangles balanced); the TLAS gets the rest at most.
-    uint32_t const tlas_limit = kStackEntries - 1u - 12u;
-    uint32_t deepest_tlas = 0;
-    int32_t const tlas_bin_root = builder.build(bin, prims.data(), sc.instance_count, 1u, 0u,
-        tlas_limit, emit_instance, deepest_tlas);
+
+    // The stack holds TLAS siblings + one marker + BLAS siblings.  The TLAS gets the levels a
+    // balanced tree over its entries needs plus six for SAH's uneven splits (the builder
+    // falls back to median splits where those run out), the BLASes the rest - at least 12
+    // levels (4 * 2^12 triangles balanced).
+    uint32_t const entry_budget = sc.instance_count + opened_entries;
+    uint32_t const tlas_limit =
+        std::min(kStackEntries - 1u - 12u, std::max(2u, ceil_log2(entry_budget) + 6u));
+    uint32_t const blas_limit = kStackEntries - 1u - tlas_limit;
 
     // One BLAS per mesh, shared by its instances.
-    uint32_t const blas_limit = kStackEntries - 1u - deepest_tlas;
+    std::vector<build_prim> prims;
     std::vector<int32_t> mesh_root(sc.mesh_count);
-    uint32_t deepest_blas = 0;
     for (uint32_t m = 0; m < sc.mesh_count; ++m) {
         rt_mesh const& mesh = sc.meshes[m];
         prims.resize(mesh.triangle_count);
@@ -581,8 +579,135 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
         uint32_t deepest = 0;
         mesh_root[m] = builder.build(bin, prims.data(), mesh.triangle_count, leaf_size, 0u,
             blas_limit, emit, deepest);
-        deepest_blas = std::max(deepest_blas, deepest);
     }
+
+    // Opening.  Instances whose world boxes overlap (the walls, floor and furniture of a room
+    // are separate meshes that all span the room) make every ray walk several BLASes from the
+    // root.  Replacing the entry with the largest world box by the two halves of its BLAS,
+    // again and again, yields TLAS leaves that are small where the scene is crowded; each
+    // points at a subtree of the shared BLAS through its own instance record, so the
+    // traversal is unchanged.  (Benthin, Woop, Wald, Afra: "Improved two-level BVHs using
+    // partial re-braiding", HPG 2017.)
+    std::vector<tlas_entry> entries;
+    entries.reserve(entry_budget);
+    for (uint32_t i = 0; i < sc.instance_count; ++i) {
+        tlas_entry e;
+        e.instance = i;
+        e.subtree = mesh_root[sc.instances[i].mesh];
+        e.object_box = mesh_bounds[sc.instances[i].mesh];
+        e.world = world_box(sc, sc.instances[i], e.object_box);
+        entries.push_back(e);
+    }
+    // Which instances stand among others: those whose box is covered kOpenOverlap times over
+    // (by surface area) by the boxes of the other instances.  A floor under a car or spheres
+    // on a plane are not; opening them only multiplies the instance records a ray has to enter.
+    static float const overlap_needed = [] {
+        char const* v = getenv("RT_HIP_OPEN_OVERLAP");  // tuning knob for experiments
+        return v ? (float) atof(v) : kOpenOverlap;
+    }();
+    std::vector<char> crowded(sc.instance_count, 0);
+    if (opened_entries > 0u) {
+        // by x-sorted sweep: instances whose x ranges do not meet cannot overlap
+        std::vector<uint32_t> by_x(sc.instance_count);
+        for (uint32_t i = 0; i < sc.instance_count; ++i) {
+            by_x[i] = i;
+        }
+        std::sort(by_x.begin(), by_x.end(), [&](uint32_t a, uint32_t b) {
+            return entries[a].world.lo[0] < entries[b].world.lo[0];
+        });
+        std::vector<double> covered(sc.instance_count, 0.0);
+        for (uint32_t a = 0; a < sc.instance_count; ++a) {
+            box3 const& ba = entries[by_x[a]].world;
+            for (uint32_t b = a + 1; b < sc.instance_count; ++b) {
+                box3 const& bb = entries[by_x[b]].world;
+                if (bb.lo[0] > ba.hi[0]) {
+                    break;
+                }
+                box3 both;
+                bool empty = false;
+                for (int k = 0; k < 3; ++k) {
+                    both.lo[k] = std::max(ba.lo[k], bb.lo[k]);
+                    both.hi[k] = std::min(ba.hi[k], bb.hi[k]);
+                    empty = empty || both.lo[k] > both.hi[k];
+                }
+                if (!empty) {
+                    covered[by_x[a]] += both.half_area();
+                    covered[by_x[b]] += both.half_area();
+                }
+            }
+        }
+        for (uint32_t i = 0; i < sc.instance_count; ++i) {
+            crowded[i] = covered[i] >= (double) overlap_needed * entries[i].world.half_area() ? 1 : 0;
+        }
+    }
+    auto area_less = [&](uint32_t a, uint32_t b) {
+        return entries[a].world.half_area() < entries[b].world.half_area();
+    };
+    std::vector<uint32_t> heap;  // entries that can still be opened, largest world box on top
+    auto offer = [&](uint32_t at) {
+        if (entries[at].subtree >= 0 && crowded[entries[at].instance]) {
+            heap.push_back(at);
+            std::push_heap(heap.begin(), heap.end(), area_less);
+        }
+    };
+    for (uint32_t i = 0; i < sc.instance_count; ++i) {
+        offer(i);
+    }
+    while (!heap.empty() && entries.size() < entry_budget) {
+        std::pop_heap(heap.begin(), heap.end(), area_less);
+        uint32_t const at = heap.back();
+        heap.pop_back();
+        tlas_entry const opened = entries[at];
+        bin_node const node = bin[(size_t) opened.subtree];
+        // the first half takes the opened entry's place, the second is appended
+        entries[at].subtree = node.child0;
+        entries[at].object_box = node.b0;
+        entries[at].world = world_box(sc, sc.instances[opened.instance], node.b0);
+        offer(at);
+        tlas_entry second = opened;
+        second.subtree = node.child1;
+        second.object_box = node.b1;
+        second.world = world_box(sc, sc.instances[opened.instance], node.b1);
+        entries.push_back(second);
+        offer((uint32_t) entries.size() - 1u);
+    }
+
+    // TLAS over the entries; its leaves become the instance records.
+    prims.resize(entries.size());
+    for (uint32_t e = 0; e < entries.size(); ++e) {
+        prims[e].bounds = entries[e].world;
+        set_centroid(prims[e]);
+        prims[e].id = e;
+    }
+    std::vector<int32_t> record_subtree;  // per instance record, until the collapse below
+    auto emit_instance = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
+        (void) count;  // TLAS leaves hold exactly one entry
+        uint32_t const first = (uint32_t) out.instances.size();
+        tlas_entry const& entry = entries[leaf[0].id];
+        rt_instance const& inst = sc.instances[entry.instance];
+        instance_rec rec{};
+        if (inst.transform >= 0) {
+            rt_mat4 const& inv = sc.inverse_transforms[inst.transform];
+            for (int c = 0; c < 4; ++c) {
+                for (int r = 0; r < 3; ++r) {
+                    rec.m[c * 3 + r] = inv.m[c][r];
+                }
+            }
+            rec.has_transform = 1;
+        } else {
+            rec.m[0] = rec.m[4] = rec.m[8] = 1.0f;
+            rec.has_transform = 0;
+        }
+        rec.blas_root = 0;  // set after the collapse
+        rec.ref_index = entry.instance;
+        out.instances.push_back(rec);
+        record_subtree.push_back(entry.subtree);
+        return first;
+    };
+    uint32_t deepest_tlas = 0;
+    int32_t const tlas_bin_root = builder.build(bin, prims.data(), (uint32_t) entries.size(), 1u,
+        0u, tlas_limit, emit_instance, deepest_tlas);
+
     // Collapse the binary trees into (up to) 4-wide nodes.  The traversal stack is shared by
     // the TLAS walk, the instance marker and the BLAS walk: split it between the two levels in
     // proportion to their binary heights (which is what each needs at least).
@@ -591,8 +716,8 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
     auto height_of = [&](int32_t ref) { return ref >= 0 ? height[(size_t) ref] : 0u; };
     uint32_t const tlas_height = height_of(tlas_bin_root);
     uint32_t blas_height = 0;
-    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
-        blas_height = std::max(blas_height, height_of(mesh_root[m]));
+    for (int32_t subtree : record_subtree) {
+        blas_height = std::max(blas_height, height_of(subtree));
     }
     uint32_t const room = kStackEntries - 1u;
     if (tlas_height + blas_height > room) {
@@ -604,23 +729,27 @@ built_accel build_wide_accel(rt_scene_desc const& sc) {
             std::min(room - tlas_height, room * blas_height / (tlas_height + blas_height)));
     }
     uint32_t need_blas = 0;
-    std::vector<int32_t> wide_root(sc.mesh_count);
-    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
-        uint32_t need = 0;
-        wide_root[m] = collapse(bin, height, mesh_root[m], blas_budget, out.nodes, need);
-        need_blas = std::max(need_blas, need);
+    // instances of one mesh opened the same way share the collapsed subtrees
+    std::vector<int32_t> wide_of(bin.size(), kNoChild);
+    for (size_t r = 0; r < out.instances.size(); ++r) {
+        int32_t const subtree = record_subtree[r];
+        if (subtree < 0) {
+            out.instances[r].blas_root = subtree;  // a single leaf
+            continue;
+        }
+        if (wide_of[(size_t) subtree] == kNoChild) {
+            uint32_t need = 0;
+            wide_of[(size_t) subtree] = collapse(bin, height, subtree, blas_budget, out.nodes, need);
+            need_blas = std::max(need_blas, need);
+        }
+        out.instances[r].blas_root = wide_of[(size_t) subtree];
     }
     uint32_t need_tlas = 0;
     out.tlas_root = collapse(bin, height, tlas_bin_root, room - need_blas, out.nodes, need_tlas);
-    for (instance_rec& rec : out.instances) {
-        rec.blas_root = wide_root[(uint32_t) rec.blas_root];  // held the mesh index so far
-    }
     out.max_stack_bound = need_tlas + 1u + need_blas;
     if (out.max_stack_bound > kStackEntries) {
         throw std::runtime_error("accel: tree does not fit the traversal stack");
     }
-    (void) deepest_tlas;
-    (void) deepest_blas;
     order_by_heat(out);
     return out;
 }

@@ -13,14 +13,19 @@ namespace rtd {
 struct built_accel {
     std::vector<wide_node> nodes;         // TLAS and every BLAS, most visited first
     std::vector<tri_pos> tris;            // leaf order; ref_index -> uploaded triangles[]
-    std::vector<instance_rec> instances;  // most visited first
+    std::vector<instance_rec> instances;  // TLAS leaves (an instance or a part of one), most visited first
     int32_t tlas_root = 0;                // node index, or an encoded leaf
     uint32_t max_stack_bound = 0;         // TLAS depth + 1 + deepest BLAS depth
 };
 
+// TLAS leaves added by opening instances (build_wide_accel splits the instances with the
+// largest world boxes into subtrees of their BLAS until this many more leaves exist).
+constexpr uint32_t kOpenedEntries = 2048;
+
 // Builds binned-SAH binary trees over the uploaded triangles (one BLAS per
-// mesh, shared by its instances) and over the instances' world boxes.
+// mesh, shared by its instances) and over the world boxes of the instances
+// or, where instances were opened, of their parts.
 // Throws std::runtime_error on malformed input.
-built_accel build_wide_accel(rt_scene_desc const& scene);
+built_accel build_wide_accel(rt_scene_desc const& scene, uint32_t opened_entries = kOpenedEntries);
 
 }  // namespace rtd

@@ -716,10 +716,31 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
 
     wavefront_params w = r.wf;
     w.sort_rays = binned ? 1u : 0u;
-    for (int a = 0; a < 3; ++a) {
-        float const extent = r.scene_hi[a] - r.scene_lo[a];
-        w.sort_lo[a] = r.scene_lo[a];
-        w.sort_scale[a] = extent > 0.0f ? (float) (1u << kBinCellsLog2) / extent : 0.0f;
+    {
+        // the grid of origin cells: kBinCellBits halvings, each of the axis whose cells are
+        // longest, so that the cells come out roughly cubic whatever the scene's proportions
+        float extent[3];
+        uint32_t bits[3] = {0, 0, 0};
+        for (int a = 0; a < 3; ++a) {
+            extent[a] = std::max(r.scene_hi[a] - r.scene_lo[a], 0.0f);
+        }
+        for (uint32_t k = 0; k < kBinCellBits; ++k) {
+            int longest = 0;
+            for (int a = 1; a < 3; ++a) {
+                if (extent[a] / (float) (1u << bits[a]) > extent[longest] / (float) (1u << bits[longest])) {
+                    longest = a;
+                }
+            }
+            ++bits[longest];
+        }
+        uint32_t shift = 0;
+        for (int a = 0; a < 3; ++a) {
+            w.sort_lo[a] = r.scene_lo[a];
+            w.sort_scale[a] = extent[a] > 0.0f ? (float) (1u << bits[a]) / extent[a] : 0.0f;
+            w.sort_top[a] = (float) ((1u << bits[a]) - 1u);
+            w.sort_shift[a] = shift;
+            shift += bits[a];
+        }
     }
     w.sc = p.sc;
     w.cam = p.cam;
@@ -1037,7 +1058,10 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
                                          std::to_string(kRefStackCapacity));
             }
         } else {
-            built_accel const accel = build_wide_accel(s);
+            // RT_HIP_OPENED_ENTRIES: tuning knob for experiments (TLAS leaves added by opening)
+            char const* const opened = getenv("RT_HIP_OPENED_ENTRIES");
+            built_accel const accel =
+                build_wide_accel(s, opened ? (uint32_t) atoi(opened) : kOpenedEntries);
             if (accel.max_stack_bound > kFastLdsEntries) {
                 throw std::runtime_error("upload_scene: rebuilt BVH exceeds the traversal stack");
             }

@@ -86,7 +86,9 @@ struct wavefront_params {
     // ray binning (sort_rays != 0): the queues regrouped by direction octant and origin cell,
     // with the rays copied next to them so that the trace launch reads them in queue order
     uint32_t sort_rays;
-    float sort_lo[3], sort_scale[3];  // cell = (origin - lo) * scale, clamped
+    float sort_lo[3], sort_scale[3];  // cell = (origin - lo) * scale, clamped to sort_top
+    float sort_top[3];                // cells along each axis - 1
+    uint32_t sort_shift[3];           // position of each axis' cell index in the bin number
     uint32_t* binned_closest;         // pids
     uint32_t* binned_shadow;
     uint16_t* bin_keys_closest;       // [queue position before binning]
@@ -384,22 +386,24 @@ __global__ void __launch_bounds__(kTileThreads) wf_scatter_kernel(wavefront_para
 // and writes each pid to the next free place of its bin (place).  Within a bin the
 // order is that of the shares, i.e. still roughly pid order.  Which lane traces which ray has
 // no influence on any result.
-constexpr uint32_t kBinCellsLog2 = 3;                                    // 8 x 8 x 8 cells
-constexpr uint32_t kBinCount = 32u << (3u * kBinCellsLog2);              // x 24 directions
+constexpr uint32_t kBinCellBits = 9;                 // 512 cells, split over the axes by extent
+constexpr uint32_t kBinCount = 32u << kBinCellBits;  // x 24 directions (numbered 0..31)
 constexpr uint32_t kBinThreads = 1024;
 
 RT_DEV uint32_t ray_bin(wavefront_params const& p, float4 o, float4 d) {
-    float const top = (float) ((1u << kBinCellsLog2) - 1u);
     // fmaxf(NaN, 0) = 0: a ray with a NaN origin lands in cell 0
-    uint32_t const cx = (uint32_t) fminf(fmaxf((o.x - p.sort_lo[0]) * p.sort_scale[0], 0.0f), top);
-    uint32_t const cy = (uint32_t) fminf(fmaxf((o.y - p.sort_lo[1]) * p.sort_scale[1], 0.0f), top);
-    uint32_t const cz = (uint32_t) fminf(fmaxf((o.z - p.sort_lo[2]) * p.sort_scale[2], 0.0f), top);
-    uint32_t const cell = cx | (cy << kBinCellsLog2) | (cz << (2u * kBinCellsLog2));
+    uint32_t const cx =
+        (uint32_t) fminf(fmaxf((o.x - p.sort_lo[0]) * p.sort_scale[0], 0.0f), p.sort_top[0]);
+    uint32_t const cy =
+        (uint32_t) fminf(fmaxf((o.y - p.sort_lo[1]) * p.sort_scale[1], 0.0f), p.sort_top[1]);
+    uint32_t const cz =
+        (uint32_t) fminf(fmaxf((o.z - p.sort_lo[2]) * p.sort_scale[2], 0.0f), p.sort_top[2]);
+    uint32_t const cell = (cx << p.sort_shift[0]) | (cy << p.sort_shift[1]) | (cz << p.sort_shift[2]);
     // direction: octant and dominant axis (24 classes, numbered 0..31)
     uint32_t const octant = (d.x < 0.0f ? 1u : 0u) | (d.y < 0.0f ? 2u : 0u) | (d.z < 0.0f ? 4u : 0u);
     float const ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     uint32_t const major = ax >= ay ? (ax >= az ? 0u : 2u) : (ay >= az ? 1u : 2u);
-    return (((major << 3) | octant) << (3u * kBinCellsLog2)) | cell;  // < kBinCount
+    return (((major << 3) | octant) << kBinCellBits) | cell;  // < kBinCount
 }
 
 // The share of workgroup `g` of `groups` in a queue of n entries: [first, last), whole chunks.

@@ -1,12 +1,15 @@
 // Host-side check of the rebuilt acceleration structure (no GPU needed): builds it for scene
 // snapshots and verifies that
 //   * the nodes form trees (every node reached exactly once, references in range),
-//   * every triangle of an instanced mesh and every instance appears in exactly one leaf,
+//   * every TLAS leaf is reached exactly once, and the BLAS subtrees of the leaves that belong
+//     to one instance (an opened instance has several) hold every triangle of its mesh
+//     exactly once,
 //   * every child box contains everything below it,
 //   * the reported stack bound equals what the deepest walk can have pending.
 // usage: validate_accel <scene.rtsnap>...      (built by __graft_entry__.build())
 #include <algorithm>
 #include <cstdio>
+#include <map>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -40,8 +43,9 @@ struct dbox {
 struct checker {
     built_accel const& acc;
     rt_scene_desc const& sc;
-    std::vector<int> node_seen, tri_seen, instance_seen;
-    std::vector<dbox> mesh_box;  // filled when a BLAS root is walked
+    std::vector<int> node_seen, instance_seen;
+    std::vector<dbox> subtree_box;         // per TLAS leaf: exact object-space bounds of its subtree
+    std::vector<uint32_t>* collect = nullptr;  // triangles seen by the BLAS walk in progress
 
     // Returns the exact bounds of everything below `ref`; `need` = pending siblings.
     dbox walk(int32_t ref, bool tlas, uint32_t& need) {
@@ -59,7 +63,7 @@ struct checker {
                 }
                 ++instance_seen[first];
                 rt_instance const& inst = sc.instances[acc.instances[first].ref_index];
-                dbox const& mb = mesh_box[inst.mesh];
+                dbox const& mb = subtree_box[first];
                 for (int corner = 0; corner < 8; ++corner) {
                     double const p[3] = {(corner & 1) ? mb.hi[0] : mb.lo[0],
                         (corner & 2) ? mb.hi[1] : mb.lo[1], (corner & 4) ? mb.hi[2] : mb.lo[2]};
@@ -79,7 +83,7 @@ struct checker {
                 }
                 for (uint32_t t = first; t < first + count; ++t) {
                     tri_pos const& tp = acc.tris[t];
-                    ++tri_seen[tp.ref_index];
+                    collect->push_back(tp.ref_index);
                     all.grow(tp.ax, tp.ay, tp.az);
                     all.grow(tp.bx, tp.by, tp.bz);
                     all.grow(tp.cx, tp.cy, tp.cz);
@@ -137,37 +141,63 @@ void validate(char const* path) {
     rt_scene_desc sc{};
     rt_host_scene_desc(scene, &sc);
     built_accel const acc = build_wide_accel(sc);
-    checker ck{acc, sc, std::vector<int>(acc.nodes.size(), 0), std::vector<int>(sc.triangle_count, 0),
-        std::vector<int>(acc.instances.size(), 0), std::vector<dbox>(sc.mesh_count)};
-    std::vector<int> mesh_done(sc.mesh_count, 0);
+    checker ck{acc, sc, std::vector<int>(acc.nodes.size(), 0),
+        std::vector<int>(acc.instances.size(), 0), std::vector<dbox>(acc.instances.size())};
+    // every distinct BLAS subtree once: its bounds, its triangles, its stack need
+    struct subtree_info {
+        dbox box;
+        std::vector<uint32_t> triangles;
+    };
+    std::map<int32_t, subtree_info> subtrees;
     uint32_t need_blas = 0;
-    for (instance_rec const& rec : acc.instances) {
-        uint32_t const mesh = sc.instances[rec.ref_index].mesh;
-        if (mesh_done[mesh]++ == 0) {
+    for (size_t r = 0; r < acc.instances.size(); ++r) {
+        int32_t const root = acc.instances[r].blas_root;
+        auto found = subtrees.find(root);
+        if (found == subtrees.end()) {
+            subtree_info info;
+            ck.collect = &info.triangles;
             uint32_t need = 0;
-            ck.mesh_box[mesh] = ck.walk(rec.blas_root, false, need);
+            info.box = ck.walk(root, false, need);
             need_blas = std::max(need_blas, need);
+            found = subtrees.emplace(root, std::move(info)).first;
+        }
+        ck.subtree_box[r] = found->second.box;
+    }
+    // per scene instance: its leaves together hold each triangle of its mesh exactly once
+    std::vector<std::vector<size_t>> leaves_of(sc.instance_count);
+    for (size_t r = 0; r < acc.instances.size(); ++r) {
+        if (acc.instances[r].ref_index >= sc.instance_count) {
+            fail("TLAS leaf refers to a missing instance");
+        }
+        leaves_of[acc.instances[r].ref_index].push_back(r);
+    }
+    std::vector<int> seen;
+    for (uint32_t i = 0; i < sc.instance_count; ++i) {
+        rt_mesh const& mesh = sc.meshes[sc.instances[i].mesh];
+        seen.assign(mesh.triangle_count, 0);
+        for (size_t r : leaves_of[i]) {
+            for (uint32_t t : subtrees[acc.instances[r].blas_root].triangles) {
+                if (t < mesh.triangle_offset || t >= mesh.triangle_offset + mesh.triangle_count) {
+                    fail("TLAS leaf holds a triangle of another mesh");
+                }
+                ++seen[t - mesh.triangle_offset];
+            }
+        }
+        for (int n : seen) {
+            if (n != 1) {
+                fail("triangle not in exactly one leaf of its instance");
+            }
         }
     }
     uint32_t need_tlas = 0;
     ck.walk(acc.tlas_root, true, need_tlas);
     size_t reached = 0;
-    for (int seen : ck.node_seen) {
-        reached += seen == 1 ? 1 : 0;
+    for (int n : ck.node_seen) {
+        reached += n == 1 ? 1 : 0;
     }
-    for (uint32_t m = 0; m < sc.mesh_count; ++m) {
-        if (mesh_done[m] == 0) {
-            continue;  // a mesh without an instance is never reached
-        }
-        for (uint32_t t = 0; t < sc.meshes[m].triangle_count; ++t) {
-            if (ck.tri_seen[sc.meshes[m].triangle_offset + t] != 1) {
-                fail("triangle not in exactly one leaf");
-            }
-        }
-    }
-    for (int seen : ck.instance_seen) {
-        if (seen != 1) {
-            fail("instance not in exactly one leaf");
+    for (int n : ck.instance_seen) {
+        if (n != 1) {
+            fail("TLAS leaf not reached exactly once");
         }
     }
     uint32_t const need = need_tlas + 1u + need_blas;
@@ -175,10 +205,10 @@ void validate(char const* path) {
         fail("stack bound " + std::to_string(acc.max_stack_bound) + " but walks need " +
              std::to_string(need));
     }
-    printf("%s: ok - %zu nodes (%zu reachable), %zu triangles, %zu instances, stack bound %u "
-           "(TLAS %u, BLAS %u)\n",
-        path, acc.nodes.size(), reached, acc.tris.size(), acc.instances.size(), need, need_tlas,
-        need_blas);
+    printf("%s: ok - %zu nodes (%zu reachable), %zu triangles, %u instances in %zu TLAS leaves, "
+           "stack bound %u (TLAS %u, BLAS %u)\n",
+        path, acc.nodes.size(), reached, acc.tris.size(), sc.instance_count, acc.instances.size(),
+        need, need_tlas, need_blas);
     rt_host_free_scene(scene);
 }
 
