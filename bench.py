@@ -77,12 +77,14 @@ def measured_traffic(kernel, args):
     if not os.path.exists(path):
         return None
     with open(path) as f:
-        t = json.load(f)
-    same = (t.get("scene") == args.scene and t.get("width") == args.width
-            and t.get("height") == args.height and t.get("max_depth") == args.max_depth
-            and t.get("spp_per_step") == args.spp_per_step and t.get("pipeline") == args.pipeline
-            and t.get("accel") == args.accel)
-    return t.get("bytes_per_launch", {}).get(kernel) if same else None
+        measured = json.load(f)
+    for t in measured if isinstance(measured, list) else [measured]:
+        if (t.get("scene") == args.scene and t.get("width") == args.width
+                and t.get("height") == args.height and t.get("max_depth") == args.max_depth
+                and t.get("spp_per_step") == args.spp_per_step
+                and t.get("pipeline") == args.pipeline and t.get("accel") == args.accel):
+            return t.get("bytes_per_launch", {}).get(kernel)
+    return None
 
 
 def cpu_baseline(sc, cam, args, tile, target_seconds):

@@ -24,7 +24,9 @@ def test_default_workload_has_traffic_and_constants(monkeypatch):
     traffic = bench.measured_traffic("wf_extend_kernel", args)
     assert traffic is not None and 1e8 < traffic < 1e10
     with open(os.path.join(ROOT, "profiles", "r01", "traffic.json")) as f:
-        assert json.load(f)["spp_per_step"] == args.spp_per_step
+        on_file = json.load(f)
+    assert any(t["scene"] == args.scene and t["spp_per_step"] == args.spp_per_step
+               for t in on_file)
     # another workload has no measurement on file: traffic must be null, not a stale number
     args.spp_per_step += 1
     assert bench.measured_traffic("wf_extend_kernel", args) is None
@@ -32,7 +34,8 @@ def test_default_workload_has_traffic_and_constants(monkeypatch):
 
 def test_workload_constants_cover_the_snapshot_scenes(monkeypatch):
     bench = load_bench(monkeypatch)
-    for scene in ("cornell_box", "hyperion_rect_light", "mustang_red_reduced"):
+    for scene in ("cornell_box", "hyperion_rect_light", "mustang_red_reduced",
+                  "staircase_reduced", "teapot_standin"):
         k = bench.load_constants(scene)
         assert k["config"] == {"width": 1280, "height": 720, "max_depth": 7, "passes": 2}
         assert k["nodes_per_ray"] > 1.0 and k["tris_per_ray"] > 0.1
