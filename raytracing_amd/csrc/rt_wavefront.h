@@ -23,7 +23,10 @@
 // scatter kernel writes the compacted lists.  The lists therefore keep pid
 // order from trip to trip - neighbouring pixels stay neighbours, which keeps the state
 // arrays' accesses coalesced and the rays of a wave coherent - and a render is
-// reproducible down to the order of its memory accesses.
+// reproducible down to the order of its memory accesses.  (Where late-bounce rays are
+// expensive, the ray queues - not the live list - are regrouped before the trace launch,
+// see "Ray binning" below; the order inside a bin then depends on the timing of LDS atomics,
+// which no result depends on.)
 //
 // The per-trip kernels run on a fixed grid of resident waves; wave w takes chunks w, w + W,
 // w + 2W ... (list lengths exist only on the device).  Work counters are kept per wave

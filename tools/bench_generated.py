@@ -57,6 +57,9 @@ def main():
         if name == "pipeline":
             e_ms, e_n = r.kernel_time(hip.KERNEL_EXTEND)
             s_ms, s_n = r.kernel_time(hip.KERNEL_SHADE)
+            state, probe_ns = r.ray_binning()
+            line += (f", ray binning {['undecided', 'off', 'on'][state]} "
+                     f"(probe {probe_ns:.2f} ns per ray)")
             line += (f", trace {e_ms * e_n / n:.2f} ms, shade {s_ms * s_n / n:.2f} ms per call; "
                      f"rays per bounce {[sum(r.trip_counts(t)[1:]) for t in range(md + 1)]}")
         print(line, flush=True)
