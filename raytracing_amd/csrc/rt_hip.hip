@@ -641,6 +641,10 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
         r.wf_shade_grid = cus * 2u;
         r.wf_finish_grid = cus * 8u;  // one-wave workgroups, two per SIMD
         r.wf_bin_groups = cus;
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_count_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
+        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_place_kernel),
+            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
         // per-wave work counters: allocated once, they outlive a regrowth of the state arrays
         size_t const stat_bytes = (size_t) std::max({r.wf_extend_waves, r.wf_shade_grid * (kShadeThreads / 64u), r.wf_finish_grid}) *
                                   kStatWords * sizeof(unsigned long long);
@@ -838,14 +842,14 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         HIP_CHECK(hipGetLastError());
         if (binned) {
             dim3 const shares(r.wf_bin_groups, 2u);
-            hipLaunchKernelGGL(wf_bin_count_kernel, shares, dim3(kBinThreads), 0, stream, w, trip);
+            hipLaunchKernelGGL(wf_bin_count_kernel, shares, dim3(kBinThreads), kBinCount * 4u, stream, w, trip);
             HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(wf_bin_columns_kernel, dim3(kBinCount / kBinColumnThreads, 2u),
                 dim3(kBinColumnThreads), 0, stream, w, trip, r.wf_bin_groups);
             HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(wf_bin_bases_kernel, dim3(2u), dim3(kBinThreads), 0, stream, w, trip);
             HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL(wf_bin_place_kernel, shares, dim3(kBinThreads), 0, stream, w, trip);
+            hipLaunchKernelGGL(wf_bin_place_kernel, shares, dim3(kBinThreads), kBinCount * 4u, stream, w, trip);
             HIP_CHECK(hipGetLastError());
         }
     };

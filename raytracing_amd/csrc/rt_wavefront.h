@@ -389,7 +389,7 @@ __global__ void __launch_bounds__(kTileThreads) wf_scatter_kernel(wavefront_para
 // and writes each pid to the next free place of its bin (place).  Within a bin the
 // order is that of the shares, i.e. still roughly pid order.  Which lane traces which ray has
 // no influence on any result.
-constexpr uint32_t kBinCellBits = 9;                 // 512 cells, split over the axes by extent
+constexpr uint32_t kBinCellBits = 10;                // 1024 cells, split over the axes by extent
 constexpr uint32_t kBinCount = 32u << kBinCellBits;  // x 24 directions (numbered 0..31)
 constexpr uint32_t kBinThreads = 1024;
 
@@ -419,7 +419,7 @@ RT_DEV void bin_share(uint32_t n, uint32_t g, uint32_t groups, uint32_t& first, 
 // grid (groups, 2): y = 0 closest-hit queue, y = 1 occlusion queue
 __global__ void __launch_bounds__(kBinThreads) wf_bin_count_kernel(wavefront_params const p,
     uint32_t trip) {
-    __shared__ uint32_t hist[kBinCount];
+    extern __shared__ uint32_t hist[];  // kBinCount words
     uint32_t const kind = blockIdx.y;
     uint32_t const n = p.control[trip * kCtlWords + (kind ? kCtlShadow : kCtlClosest)];
     if (n == 0u) {
@@ -520,7 +520,7 @@ __global__ void __launch_bounds__(kBinThreads) wf_bin_bases_kernel(wavefront_par
 // grid (groups, 2), the same shares as the count launch
 __global__ void __launch_bounds__(kBinThreads) wf_bin_place_kernel(wavefront_params const p,
     uint32_t trip) {
-    __shared__ uint32_t cursor[kBinCount];
+    extern __shared__ uint32_t cursor[];  // kBinCount words
     uint32_t const kind = blockIdx.y;
     uint32_t const n = p.control[trip * kCtlWords + (kind ? kCtlShadow : kCtlClosest)];
     if (n == 0u) {
