@@ -54,8 +54,9 @@ enum {
      * so that a wave traces rays that start in the same part of the scene and point the same
      * way.  Pays off on scenes whose incoherent rays are expensive to trace (interiors), costs
      * a few percent on scenes whose rays are cheap; images are bit-identical either way.
-     * Default (neither flag): decided per uploaded scene from the measured cost of tracing
-     * its third bounce, see rt_hip_ray_binning.  The flags force it on or off. */
+     * Default (neither flag): decided per uploaded scene and per bounce from the measured
+     * cost of tracing that bounce's rays in the first large render call, see
+     * rt_hip_ray_binning.  The flags force it on (every bounce) or off. */
     RT_HIP_FLAG_BIN_RAYS = 8u,
     RT_HIP_FLAG_NO_BIN_RAYS = 16u
 };
@@ -172,9 +173,10 @@ int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
 int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts);
 
 /* Diagnostics of the pipeline: whether ray binning is in use for the uploaded scene
- * (RT_HIP_BINNING_*) and, when it was decided by measurement, the measured cost of tracing
- * one ray of the third bounce without binning, in nanoseconds of whole-GPU time (0 when
- * forced by a flag or not yet measured).  No counterpart in the reference. */
+ * (RT_HIP_BINNING_*: ON = for at least one bounce) and, when it was decided by measurement,
+ * the measured cost of tracing one ray of the third bounce without binning, in nanoseconds
+ * of whole-GPU time (0 when forced by a flag or not yet measured).  No counterpart in the
+ * reference. */
 int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per_ray);
 
 /* Replaces megakernel_raytracer_destroy (:793-813). */

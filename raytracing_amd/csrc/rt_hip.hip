@@ -357,13 +357,17 @@ struct rt_hip_renderer {
     bool wf_binned = false;           // the binning buffers exist
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};  // world bounds of the scene
     // Ray binning policy for the uploaded scene (RT_HIP_BINNING_*).  Undecided: the next
-    // large enough render call runs without binning and times the trace launch of trip
-    // kProbeTrip; the call after that reads the result.
+    // large enough render call runs without binning and times the trace launch of every
+    // trip; the call after that reads the result and decides trip by trip.
     uint32_t binning = RT_HIP_BINNING_UNDECIDED;
+    std::vector<char> bin_trip;        // per trip: regroup its ray queues (when binning is ON)
     bool probe_pending = false;
-    hipEvent_t probe_start = nullptr, probe_stop = nullptr, probe_done = nullptr;
-    uint32_t* probe_counts = nullptr;  // pinned: closest-hit and occlusion rays of the probe trip
-    double probe_ns_per_ray = 0.0;
+    uint32_t probe_trips = 0;          // trips timed by the probe in flight
+    std::vector<hipEvent_t> probe_events;  // 2 per trip (start, stop), created on demand
+    hipEvent_t probe_done = nullptr;
+    uint32_t* probe_counts = nullptr;  // pinned copy of the control block: [trip][kCtlWords]
+    uint32_t probe_counts_trips = 0;
+    double probe_ns_per_ray = 0.0;     // of trip kProbeTrip (reported by rt_hip_ray_binning)
 
     struct timed_launch {
         hipEvent_t start, stop;
@@ -585,12 +589,19 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
 // faster per sample than 16.
 constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 26;
 
-// Ray binning is worth its launches when tracing a late-bounce ray costs more than this many
-// nanoseconds of whole-GPU time (measured on MI355X: staircase interior 0.72 -> binning makes
-// the render 1.45x faster; mustang 0.3 -> +4 %; hyperion 0.15 -> -10 %; Cornell box 0.08).
-constexpr double kBinningPaysAboveNs = 0.4;
-constexpr uint32_t kProbeTrip = 2;            // first trip whose rays have all left a bounce
-constexpr uint32_t kProbeMinRays = 4u << 20;  // fewer rays than this time the launch, not the rays
+// Regrouping a trip's ray queues is worth its launches when tracing one of its rays costs more
+// than kBinningPaysAboveNs nanoseconds of whole-GPU time and the trip has enough rays to pay for
+// the fixed part (four small launches).  Measured on MI355X at 64 passes of 1280x720, unbinned
+// cost per ray -> change of that trip's trace launch with binning:
+//   staircase interior   bounce 1: 0.56 ns -> -8 %, bounces 2-7: 0.72-0.8 ns -> -40 %
+//   mustang              bounce 1: 0.25 ns -> -23 %, bounce 2: 0.46 ns -> -33 %
+//   hyperion             bounce 1: 0.09 ns -> +12 % (slower), bounces 2-3: 0.29 ns, 6.5 and 4.2 M
+//                        rays -> -12 % / +10 %, a wash after the sort's own time
+//   Cornell box          0.08-0.11 ns -> slower
+constexpr double kBinningPaysAboveNs = 0.2;
+constexpr uint32_t kBinningMinRays = 8u << 20;  // per trip
+constexpr uint32_t kProbeTrip = 2;              // the trip whose cost rt_hip_ray_binning reports
+constexpr uint32_t kProbeMinPaths = 4u << 20;   // smaller batches time the launches, not the rays
 
 // Settles an outstanding probe if its events have completed (never waits).
 void settle_binning_probe(rt_hip_renderer& r) {
@@ -598,14 +609,21 @@ void settle_binning_probe(rt_hip_renderer& r) {
         return;
     }
     r.probe_pending = false;
-    float ms = 0.0f;
-    HIP_CHECK(hipEventElapsedTime(&ms, r.probe_start, r.probe_stop));
-    uint64_t const rays = (uint64_t) r.probe_counts[0] + r.probe_counts[1];
-    if (rays < kProbeMinRays) {
-        return;  // handed over to the finishing kernel, or a small frame: stay undecided
+    r.bin_trip.assign(r.probe_trips, 0);
+    bool any = false;
+    for (uint32_t trip = 1; trip < r.probe_trips; ++trip) {
+        float ms = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms, r.probe_events[2 * trip], r.probe_events[2 * trip + 1]));
+        const uint32_t* const ctl = r.probe_counts + trip * kCtlWords;
+        uint64_t const rays = (uint64_t) ctl[kCtlClosest] + ctl[kCtlShadow];
+        double const ns = rays > 0 ? (double) ms * 1e6 / (double) rays : 0.0;
+        if (trip == kProbeTrip) {
+            r.probe_ns_per_ray = ns;
+        }
+        r.bin_trip[trip] = rays >= kBinningMinRays && ns > kBinningPaysAboveNs ? 1 : 0;
+        any = any || r.bin_trip[trip] != 0;
     }
-    r.probe_ns_per_ray = (double) ms * 1e6 / (double) rays;
-    r.binning = r.probe_ns_per_ray > kBinningPaysAboveNs ? RT_HIP_BINNING_ON : RT_HIP_BINNING_OFF;
+    r.binning = any ? RT_HIP_BINNING_ON : RT_HIP_BINNING_OFF;
 }
 
 void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool binned) {
@@ -713,13 +731,32 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     uint32_t const trips = p.max_depth + 1u;
     settle_binning_probe(r);
     bool const binned = r.binning == RT_HIP_BINNING_ON;
+    // trips beyond those measured (a forced ON has measured none) are binned
+    auto trip_binned = [&](uint32_t trip) {
+        return binned && trip >= 1u && (trip >= r.bin_trip.size() || r.bin_trip[trip] != 0);
+    };
     // measure this call?  (one batch is enough; a probe in flight is left alone)
-    bool probe = r.binning == RT_HIP_BINNING_UNDECIDED && !r.probe_pending && trips > kProbeTrip &&
-                 per_pass * batch >= kProbeMinRays;
+    bool probe = r.binning == RT_HIP_BINNING_UNDECIDED && !r.probe_pending && trips > 1u &&
+                 per_pass * batch >= kProbeMinPaths;
+    if (probe) {
+        while (r.probe_events.size() < 2u * trips) {
+            hipEvent_t e = nullptr;
+            HIP_CHECK(hipEventCreate(&e));
+            r.probe_events.push_back(e);
+        }
+        if (r.probe_counts_trips < trips) {
+            if (r.probe_counts) {
+                HIP_CHECK(hipHostFree(r.probe_counts));
+                r.probe_counts = nullptr;
+            }
+            HIP_CHECK(hipHostMalloc((void**) &r.probe_counts, (size_t) trips * kCtlWords * 4));
+            r.probe_counts_trips = trips;
+        }
+    }
     ensure_wavefront(r, per_pass * batch, trips, binned);
 
     wavefront_params w = r.wf;
-    w.sort_rays = binned ? 1u : 0u;
+    w.sort_rays = 0u;  // set per trip below
     {
         // the grid of origin cells: kBinCellBits halvings, each of the axis whose cells are
         // longest, so that the cells come out roughly cubic whatever the scene's proportions
@@ -840,7 +877,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         hipLaunchKernelGGL(wf_scatter_kernel, tiles, dim3(kTileThreads), 0, stream, w,
             in_count_ptr, in_count);
         HIP_CHECK(hipGetLastError());
-        if (binned) {
+        if (trip_binned(trip)) {
             dim3 const shares(r.wf_bin_groups, 2u);
             hipLaunchKernelGGL(wf_bin_count_kernel, shares, dim3(kBinThreads), kBinCount * 4u, stream, w, trip);
             HIP_CHECK(hipGetLastError());
@@ -875,18 +912,22 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
             if (each) {
                 t = r.begin_timing(stream, RT_HIP_KERNEL_EXTEND);
             }
-            bool const probe_here = probe && trip == kProbeTrip;
+            bool const probe_here = probe && trip >= 1u;
             if (probe_here) {
-                HIP_CHECK(hipEventRecord(r.probe_start, stream));
+                HIP_CHECK(hipEventRecord(r.probe_events[2 * trip], stream));
             }
+            w.sort_rays = trip_binned(trip) ? 1u : 0u;
             extend(trip, trip == 0u ? chunk_bound : 2u * chunk_bound);
             if (probe_here) {
-                HIP_CHECK(hipEventRecord(r.probe_stop, stream));
-                HIP_CHECK(hipMemcpyAsync(r.probe_counts, w.control + trip * kCtlWords + kCtlClosest,
-                    2 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                HIP_CHECK(hipEventRecord(r.probe_done, stream));
-                r.probe_pending = true;
-                probe = false;
+                HIP_CHECK(hipEventRecord(r.probe_events[2 * trip + 1], stream));
+                if (trip + 1u == trips) {
+                    HIP_CHECK(hipMemcpyAsync(r.probe_counts, w.control,
+                        (size_t) trips * kCtlWords * 4, hipMemcpyDeviceToHost, stream));
+                    HIP_CHECK(hipEventRecord(r.probe_done, stream));
+                    r.probe_pending = true;
+                    r.probe_trips = trips;
+                    probe = false;
+                }
             }
             if (each) {
                 r.end_timing(t, stream);
@@ -1003,10 +1044,7 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         HIP_CHECK(hipMalloc((void**) &r->block_cost, r->block_total * sizeof(uint32_t)));
         HIP_CHECK(hipMalloc((void**) &r->block_order, r->block_total * sizeof(uint32_t)));
         HIP_CHECK(hipMemset(r->block_cost, 0, r->block_total * sizeof(uint32_t)));
-        HIP_CHECK(hipEventCreate(&r->probe_start));
-        HIP_CHECK(hipEventCreate(&r->probe_stop));
         HIP_CHECK(hipEventCreate(&r->probe_done));
-        HIP_CHECK(hipHostMalloc((void**) &r->probe_counts, 2 * sizeof(uint32_t)));
         *out = r.release();
     });
 }
@@ -1094,6 +1132,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         // experiments), otherwise measured on this scene by the next large render call
         r->probe_pending = false;  // the device was synchronised above
         r->probe_ns_per_ray = 0.0;
+        r->bin_trip.clear();
         char const* const forced = getenv("RT_HIP_BIN_RAYS");
         if (r->cfg.accel != RT_HIP_ACCEL_REBUILT || (r->cfg.flags & RT_HIP_FLAG_NO_BIN_RAYS) ||
             (forced && atoi(forced) == 0)) {
@@ -1490,10 +1529,13 @@ int rt_hip_destroy(rt_hip_renderer* r) {
             (void) hipEventDestroy(t.start);
             (void) hipEventDestroy(t.stop);
         }
-        (void) hipEventDestroy(r->probe_start);
-        (void) hipEventDestroy(r->probe_stop);
+        for (hipEvent_t e : r->probe_events) {
+            (void) hipEventDestroy(e);
+        }
         (void) hipEventDestroy(r->probe_done);
-        (void) hipHostFree(r->probe_counts);
+        if (r->probe_counts) {
+            (void) hipHostFree(r->probe_counts);
+        }
         (void) hipFree(r->accum);
         (void) hipFree(r->preview);
         (void) hipFree(r->counters);

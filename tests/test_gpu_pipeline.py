@@ -114,9 +114,10 @@ def test_batches_of_passes(hyperion, binning):
 
 def test_ray_binning_is_decided_by_measurement(cornell, staircase):
     """Without a forcing flag the first large render call of a scene runs unbinned and times
-    the trace launch of its third bounce; the next call reads the result.  Tracing an
-    incoherent ray costs about 0.7 ns of GPU time in the staircase interior and 0.1 ns in the
-    Cornell box, against a threshold of 0.4; the switch does not change a bit of the image."""
+    its trace launches; the next call reads the result and bins the bounces whose rays are
+    expensive.  Tracing a third-bounce ray costs about 0.45-0.7 ns of GPU time in the staircase
+    interior and 0.1 ns in the Cornell box, against a threshold of 0.2; the switch does not
+    change a bit of the image."""
     w, h, md, tile, spp = 640, 800, 7, (64, 80), 12
     outcome = {}
     for name, scene in (("cornell", cornell), ("staircase", staircase)):
