@@ -118,7 +118,7 @@ def test_ray_binning_is_decided_by_measurement(cornell, staircase):
     expensive.  Tracing a third-bounce ray costs about 0.45-0.7 ns of GPU time in the staircase
     interior and 0.1 ns in the Cornell box, against a threshold of 0.2; the switch does not
     change a bit of the image."""
-    w, h, md, tile, spp = 640, 800, 7, (64, 80), 12
+    w, h, md, tile, spp = 640, 800, 7, (64, 80), 16
     outcome = {}
     for name, scene in (("cornell", cornell), ("staircase", staircase)):
         r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
