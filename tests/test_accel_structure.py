@@ -14,10 +14,11 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TOOL = os.path.join(ROOT, "raytracing_amd", "bin", "validate_accel")
 
 
-def run_tool(paths):
+def run_tool(paths, env=None):
     if not os.path.exists(TOOL):
         pytest.fail(f"{TOOL} is missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
-    out = subprocess.run([TOOL] + paths, capture_output=True, text=True, timeout=300)
+    out = subprocess.run([TOOL] + paths, capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, **(env or {})))
     assert out.returncode == 0, out.stdout + out.stderr
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == len(paths) and all(": ok - " in l for l in lines), out.stdout
@@ -45,3 +46,27 @@ def test_generated_scenes(tmp_path):
     tex.save_snapshot(paths[1])
     lines = run_tool(paths)
     assert "1604 instances" in lines[0]
+
+
+def leaves_of(line):
+    return int(line.split(" instances in ")[1].split()[0])
+
+
+def test_instance_opening():
+    """Instances that stand inside other instances' boxes are opened into subtrees of their
+    BLAS (one TLAS leaf each); the checker verifies that the leaves of an instance still hold
+    each of its triangles exactly once.  With the default gate only the staircase interior
+    qualifies; with the gate at zero every scene is opened, up to the budget or until only
+    single BLAS leaves are left."""
+    names = ["cornell_box", "hyperion_rect_light", "mustang_red_reduced", "staircase_reduced",
+             "teapot_standin"]
+    paths = [scenes.snapshot_path(n) for n in names]
+    default = dict(zip(names, map(leaves_of, run_tool(paths))))
+    assert default == {"cornell_box": 8, "hyperion_rect_light": 28, "mustang_red_reduced": 5,
+                       "staircase_reduced": 20 + 2048, "teapot_standin": 2}
+    opened = run_tool(paths, env={"RT_HIP_OPEN_OVERLAP": "0"})
+    every = dict(zip(names, map(leaves_of, opened)))
+    assert every["cornell_box"] == 18          # 36 triangles in leaves of two
+    assert every["hyperion_rect_light"] == 28 + 2048 and every["teapot_standin"] == 2 + 2048
+    for line in opened:
+        assert 1 <= int(line.split("stack bound ")[1].split()[0]) <= 40, line
