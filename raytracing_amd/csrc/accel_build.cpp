@@ -601,10 +601,8 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
     // Which instances stand among others: those whose box is covered kOpenOverlap times over
     // (by surface area) by the boxes of the other instances.  A floor under a car or spheres
     // on a plane are not; opening them only multiplies the instance records a ray has to enter.
-    static float const overlap_needed = [] {
-        char const* v = getenv("RT_HIP_OPEN_OVERLAP");  // tuning knob for experiments
-        return v ? (float) atof(v) : kOpenOverlap;
-    }();
+    char const* const gate = getenv("RT_HIP_OPEN_OVERLAP");  // tuning knob for experiments
+    float const overlap_needed = gate ? (float) atof(gate) : kOpenOverlap;
     std::vector<char> crowded(sc.instance_count, 0);
     if (opened_entries > 0u) {
         // by x-sorted sweep: instances whose x ranges do not meet cannot overlap

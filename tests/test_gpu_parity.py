@@ -133,6 +133,16 @@ def test_primary_ids_teapot(teapot, accel):
     check_ids(teapot, 640, 360, (128, 72), accel)
 
 
+@pytest.mark.parametrize("scene_name", ["cornell", "hyperion", "mustang", "teapot"])
+def test_primary_ids_with_every_instance_opened(request, monkeypatch, scene_name):
+    """The acceleration structure opens crowded instances into subtrees of their BLAS; by
+    default only the staircase qualifies.  With the gate at zero every scene gets ~2 000 TLAS
+    leaves; hits must not change (same triangles, same object-space arithmetic)."""
+    monkeypatch.setenv("RT_HIP_OPEN_OVERLAP", "0")
+    sc = request.getfixturevalue(scene_name)
+    check_ids(sc, 640, 360, (128, 72), hip.ACCEL_REBUILT)
+
+
 @pytest.mark.parametrize("accel", ACCELS)
 def test_primary_ids_instanced_scene_beyond_reference_limits(instanced, accel):
     # 1604 instances: rays cross far more than the shader's 15-entry candidate list
