@@ -413,6 +413,7 @@ struct rt_hip_renderer {
         wf_allocs.clear();
         wf_paths = 0;
         wf_trips = 0;
+        wf_binned = false;
     }
 
     timed_launch begin_timing(hipStream_t stream, uint32_t kind = RT_HIP_KERNEL_RENDER) {
@@ -669,7 +670,26 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
         HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
         HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
     }
-    if (paths <= r.wf_paths && trips <= r.wf_trips && (r.wf_binned || !binned)) {
+    auto alloc = [&](size_t bytes) {
+        void* d = nullptr;
+        HIP_CHECK(hipMalloc(&d, bytes));
+        r.wf_allocs.push_back(d);
+        return d;
+    };
+    auto alloc_binning = [&](size_t for_paths) {
+        wavefront_params& w = r.wf;
+        w.binned_closest = (uint32_t*) alloc(for_paths * 4);
+        w.binned_shadow = (uint32_t*) alloc(for_paths * 4);
+        w.bin_keys_closest = (uint16_t*) alloc(for_paths * 2);
+        w.bin_keys_shadow = (uint16_t*) alloc(for_paths * 2);
+        w.bin_hist = (uint32_t*) alloc((size_t) 2u * kBinCount * r.wf_bin_groups * 4);
+        w.bin_total = (uint32_t*) alloc((size_t) 2u * kBinCount * 4);
+        r.wf_binned = true;
+    };
+    if (paths <= r.wf_paths && trips <= r.wf_trips) {
+        if (binned && !r.wf_binned) {
+            alloc_binning(r.wf_paths);  // binning was switched on: add its buffers, keep the rest
+        }
         return;
     }
     paths = std::max(paths, r.wf_paths);
@@ -677,12 +697,6 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
     binned = binned || r.wf_binned;
     HIP_CHECK(hipDeviceSynchronize());
     r.free_wavefront();
-    auto alloc = [&](size_t bytes) {
-        void* d = nullptr;
-        HIP_CHECK(hipMalloc(&d, bytes));
-        r.wf_allocs.push_back(d);
-        return d;
-    };
     wavefront_params& w = r.wf;
     w.ray_o = (float4*) alloc(paths * 16);
     w.ray_d = (float4*) alloc(paths * 16);
@@ -702,17 +716,11 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
     w.chunk_counts = (uint32_t*) alloc(chunks * 4);
     w.tile_sums = (uint32_t*) alloc(((chunks + kTileChunks - 1u) / kTileChunks) * 12);
     w.control = (uint32_t*) alloc((size_t) (trips + 1u) * kCtlWords * 4);
-    if (binned) {
-        w.binned_closest = (uint32_t*) alloc(paths * 4);
-        w.binned_shadow = (uint32_t*) alloc(paths * 4);
-        w.bin_keys_closest = (uint16_t*) alloc(paths * 2);
-        w.bin_keys_shadow = (uint16_t*) alloc(paths * 2);
-        w.bin_hist = (uint32_t*) alloc((size_t) 2u * kBinCount * r.wf_bin_groups * 4);
-        w.bin_total = (uint32_t*) alloc((size_t) 2u * kBinCount * 4);
-    }
     r.wf_paths = paths;
     r.wf_trips = trips;
-    r.wf_binned = binned;
+    if (binned) {
+        alloc_binning(paths);
+    }
 }
 
 // rt_hip_render through the wavefront pipeline (rt_wavefront.h).
