@@ -448,6 +448,155 @@ void set_centroid(build_prim& p) {
     }
 }
 
+// Pre-splitting of large triangles ("early split clipping", Ernst and Greiner 2007).  A few
+// triangles far larger than the rest (the walls and floor of a room among its furniture) end
+// up in leaves whose boxes span the scene, and every ray has to test them.  Before the build,
+// the references with the largest boxes are cut in two at the middle of their box's longest
+// axis - the triangle clipped to either half - until a budget of extra references is used up
+// or the largest box is no longer far above the median.  Each part is an ordinary build
+// primitive with the part's (slightly padded) box; leaves hold whole triangles, so a triangle
+// may be listed in several leaves and a ray may test it twice, with identical results.
+struct tri_part {
+    float poly[10][3];  // the triangle clipped to the part's box: at most 9 corners
+    int corners;
+    box3 box;
+    uint32_t id;
+};
+
+// Clips a convex polygon to coordinate[axis] <= pos (keep_low) or >= pos.
+int clip_polygon(float const (*in)[3], int n, int axis, float pos, bool keep_low,
+    float (*out)[3]) {
+    int m = 0;
+    for (int i = 0; i < n && m < 10; ++i) {
+        float const* a = in[i];
+        float const* b = in[(i + 1) % n];
+        bool const a_in = keep_low ? a[axis] <= pos : a[axis] >= pos;
+        bool const b_in = keep_low ? b[axis] <= pos : b[axis] >= pos;
+        if (a_in) {
+            out[m][0] = a[0], out[m][1] = a[1], out[m][2] = a[2];
+            ++m;
+        }
+        if (a_in != b_in && m < 10) {
+            float const t = (pos - a[axis]) / (b[axis] - a[axis]);
+            for (int k = 0; k < 3; ++k) {
+                out[m][k] = a[k] + t * (b[k] - a[k]);
+            }
+            out[m][axis] = pos;
+            ++m;
+        }
+    }
+    return m;
+}
+
+void set_part_box(tri_part& part, box3 const& within, bool padded) {
+    box3 b;
+    for (int i = 0; i < part.corners; ++i) {
+        b.grow(part.poly[i]);
+    }
+    for (int a = 0; a < 3; ++a) {
+        if (padded) {
+            // the cut points are rounded: never let rounding shave the box
+            float const pad = 1e-6f * (b.hi[a] - b.lo[a]) +
+                              4e-7f * std::max(std::fabs(b.lo[a]), std::fabs(b.hi[a])) + 1e-30f;
+            b.lo[a] -= pad;
+            b.hi[a] += pad;
+        }
+        b.lo[a] = std::max(b.lo[a], within.lo[a]);
+        b.hi[a] = std::min(b.hi[a], within.hi[a]);
+    }
+    part.box = b;
+}
+
+constexpr float kPresplitAboveMedian = 4.0f;  // only boxes this many times the median area
+constexpr uint32_t kPresplitBudgetShift = 3;   // at most triangles / 8 extra references
+
+// The build primitives of one mesh: one per triangle, the largest ones cut into parts.
+void mesh_primitives(rt_scene_desc const& sc, rt_mesh const& mesh, std::vector<build_prim>& prims) {
+    std::vector<tri_part> parts(mesh.triangle_count);
+    std::vector<float> areas(mesh.triangle_count);
+    box3 const everything = [] {
+        box3 b;
+        for (int a = 0; a < 3; ++a) {
+            b.lo[a] = std::numeric_limits<float>::lowest();
+            b.hi[a] = std::numeric_limits<float>::max();
+        }
+        return b;
+    }();
+    for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+        rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
+        tri_part& part = parts[t];
+        for (int k = 0; k < 3; ++k) {
+            part.poly[0][k] = tri.a.position_texu[k];
+            part.poly[1][k] = tri.b.position_texu[k];
+            part.poly[2][k] = tri.c.position_texu[k];
+        }
+        part.corners = 3;
+        part.id = mesh.triangle_offset + t;
+        set_part_box(part, everything, false);
+        areas[t] = part.box.half_area();
+    }
+    // RT_HIP_PRESPLIT: tuning knob - 0 disables, another number replaces kPresplitAboveMedian
+    char const* const knob = getenv("RT_HIP_PRESPLIT");
+    float const above_median = knob ? (float) atof(knob) : kPresplitAboveMedian;
+    uint32_t budget = above_median > 0.0f ? mesh.triangle_count >> kPresplitBudgetShift : 0u;
+    if (budget > 0u && mesh.triangle_count >= 8u) {
+        std::nth_element(areas.begin(), areas.begin() + areas.size() / 2, areas.end());
+        float const large = above_median * areas[areas.size() / 2];
+        auto smaller = [&](uint32_t a, uint32_t b) {
+            return parts[a].box.half_area() < parts[b].box.half_area();
+        };
+        std::vector<uint32_t> heap;
+        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+            if (parts[t].box.half_area() > large) {
+                heap.push_back(t);
+            }
+        }
+        std::make_heap(heap.begin(), heap.end(), smaller);
+        while (!heap.empty() && budget > 0u) {
+            std::pop_heap(heap.begin(), heap.end(), smaller);
+            uint32_t const at = heap.back();
+            heap.pop_back();
+            tri_part const whole = parts[at];
+            int axis = 0;
+            for (int a = 1; a < 3; ++a) {
+                if (whole.box.hi[a] - whole.box.lo[a] > whole.box.hi[axis] - whole.box.lo[axis]) {
+                    axis = a;
+                }
+            }
+            float const pos = 0.5f * (whole.box.lo[axis] + whole.box.hi[axis]);
+            if (!(pos > whole.box.lo[axis] && pos < whole.box.hi[axis])) {
+                continue;  // too thin to cut
+            }
+            tri_part low = whole, high = whole;
+            low.corners = clip_polygon(whole.poly, whole.corners, axis, pos, true, low.poly);
+            high.corners = clip_polygon(whole.poly, whole.corners, axis, pos, false, high.poly);
+            if (low.corners < 3 || high.corners < 3 || low.corners > 9 || high.corners > 9) {
+                continue;  // degenerate: leave this one whole
+            }
+            box3 low_half = whole.box, high_half = whole.box;
+            low_half.hi[axis] = pos;
+            high_half.lo[axis] = pos;
+            set_part_box(low, low_half, true);
+            set_part_box(high, high_half, true);
+            parts[at] = low;
+            parts.push_back(high);
+            --budget;
+            for (uint32_t piece : {at, (uint32_t) parts.size() - 1u}) {
+                if (parts[piece].box.half_area() > large) {
+                    heap.push_back(piece);
+                    std::push_heap(heap.begin(), heap.end(), smaller);
+                }
+            }
+        }
+    }
+    prims.resize(parts.size());
+    for (size_t i = 0; i < parts.size(); ++i) {
+        prims[i].bounds = parts[i].box;
+        set_centroid(prims[i]);
+        prims[i].id = parts[i].id;
+    }
+}
+
 // World box of an object-space box under an instance's transform: the 8 transformed corners,
 // padded so that rounding cannot cut a hit off.
 box3 world_box(rt_scene_desc const& sc, rt_instance const& inst, box3 const& ob) {
@@ -496,7 +645,7 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
     if (sc.instance_count == 0 || sc.mesh_count == 0 || sc.triangle_count == 0) {
         throw std::runtime_error("accel: empty scene");
     }
-    if (sc.triangle_count >= (1u << 28)) {
+    if (sc.triangle_count >= (1u << 27)) {  // leaves may list a cut triangle more than once
         throw std::runtime_error("accel: too many triangles for the leaf encoding");
     }
     built_accel out;
@@ -541,17 +690,7 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
     std::vector<int32_t> mesh_root(sc.mesh_count);
     for (uint32_t m = 0; m < sc.mesh_count; ++m) {
         rt_mesh const& mesh = sc.meshes[m];
-        prims.resize(mesh.triangle_count);
-        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
-            rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
-            build_prim& p = prims[t];
-            p.bounds = box3{};
-            p.bounds.grow(tri.a.position_texu);
-            p.bounds.grow(tri.b.position_texu);
-            p.bounds.grow(tri.c.position_texu);
-            set_centroid(p);
-            p.id = mesh.triangle_offset + t;
-        }
+        mesh_primitives(sc, mesh, prims);
         auto emit = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
             uint32_t const first = (uint32_t) out.tris.size();
             for (uint32_t i = 0; i < count; ++i) {
@@ -573,11 +712,11 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
         };
         // Leaves of 4; meshes too large for the remaining levels get leaves of 8.
         uint32_t leaf_size = 4u;
-        if (((uint64_t) leaf_size << (blas_limit > 1u ? blas_limit - 1u : 0u)) < mesh.triangle_count) {
+        if (((uint64_t) leaf_size << (blas_limit > 1u ? blas_limit - 1u : 0u)) < prims.size()) {
             leaf_size = 8u;
         }
         uint32_t deepest = 0;
-        mesh_root[m] = builder.build(bin, prims.data(), mesh.triangle_count, leaf_size, 0u,
+        mesh_root[m] = builder.build(bin, prims.data(), (uint32_t) prims.size(), leaf_size, 0u,
             blas_limit, emit, deepest);
     }
 

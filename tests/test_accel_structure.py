@@ -1,8 +1,10 @@
 """The acceleration structure the HIP library rebuilds at upload (4-wide nodes over a
 binned-SAH tree, hottest nodes first), checked on the host without a GPU by
-bin/validate_accel: nodes form trees, every triangle and instance sits in exactly one leaf,
-every child box contains what is below it, and the traversal-stack bound the kernels rely on
-equals what the deepest walk can have pending."""
+bin/validate_accel: nodes form trees, every TLAS leaf is reached once, every child box contains
+the boxes below it, the leaves of an instance list every triangle of its mesh, sample points on
+every triangle are led to a leaf that lists it (large triangles are cut into parts with boxes
+of their own), and the traversal-stack bound the kernels rely on equals what the deepest walk
+can have pending."""
 import os
 import subprocess
 
