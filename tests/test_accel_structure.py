@@ -72,3 +72,19 @@ def test_instance_opening():
     assert every["hyperion_rect_light"] == 28 + 2048 and every["teapot_standin"] == 2 + 2048
     for line in opened:
         assert 1 <= int(line.split("stack bound ")[1].split()[0]) <= 40, line
+
+
+def test_large_triangles_are_cut_into_parts():
+    """The staircase's walls and floor are a few triangles among 88 k small ones: they are
+    listed in several leaves (one per part).  Uniformly tessellated scenes are left alone, and
+    RT_HIP_PRESPLIT=0 switches the cutting off."""
+    def listings(line):
+        triangles = int(line.split(" triangles listed ")[0].split()[-1])
+        return triangles, int(line.split(" triangles listed ")[1].split()[0])
+
+    paths = [scenes.snapshot_path(n) for n in ("staircase_reduced", "teapot_standin")]
+    stair, teapot = map(listings, run_tool(paths))
+    assert stair[0] == 88433 and stair[0] * 1.03 < stair[1] <= stair[0] * 1.125 + 20
+    assert teapot[1] == teapot[0]
+    plain, _ = map(listings, run_tool(paths, env={"RT_HIP_PRESPLIT": "0"}))
+    assert plain[1] == plain[0]
