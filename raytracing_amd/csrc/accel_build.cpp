@@ -64,6 +64,8 @@ constexpr float kIntersectCost = 1.0f;
 // An instance may be opened when the boxes of the other instances cover its own box at least
 // this many times over, by surface area.
 constexpr float kOpenOverlap = 3.0f;
+constexpr uint32_t kMinOpenedEntries = 2048;
+constexpr uint32_t kTrianglesPerOpenedEntry = 10;
 
 int32_t encode_leaf(uint32_t first, uint32_t count) {
     return (int32_t) ~((first << 3) | (count - 1u));
@@ -641,7 +643,7 @@ struct tlas_entry {
 
 }  // namespace
 
-built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
+built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entries) {
     if (sc.instance_count == 0 || sc.mesh_count == 0 || sc.triangle_count == 0) {
         throw std::runtime_error("accel: empty scene");
     }
@@ -674,6 +676,63 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
             (inst.transform >= 0 && (uint32_t) inst.transform >= sc.transform_count)) {
             throw std::runtime_error("accel: instance refers to a missing mesh or transform");
         }
+    }
+
+    // Which instances stand among others: those whose box is covered kOpenOverlap times over
+    // (by surface area) by the boxes of the other instances.  A floor under a car or spheres
+    // on a plane are not; opening them only multiplies the instance records a ray has to enter.
+    char const* const gate = getenv("RT_HIP_OPEN_OVERLAP");  // tuning knob for experiments
+    float const overlap_needed = gate ? (float) atof(gate) : kOpenOverlap;
+    std::vector<box3> instance_world(sc.instance_count);
+    for (uint32_t i = 0; i < sc.instance_count; ++i) {
+        instance_world[i] = world_box(sc, sc.instances[i], mesh_bounds[sc.instances[i].mesh]);
+    }
+    std::vector<char> crowded(sc.instance_count, 0);
+    uint64_t crowded_triangles = 0;
+    if (max_opened_entries > 0u) {
+        // by x-sorted sweep: instances whose x ranges do not meet cannot overlap
+        std::vector<uint32_t> by_x(sc.instance_count);
+        for (uint32_t i = 0; i < sc.instance_count; ++i) {
+            by_x[i] = i;
+        }
+        std::sort(by_x.begin(), by_x.end(), [&](uint32_t a, uint32_t b) {
+            return instance_world[a].lo[0] < instance_world[b].lo[0];
+        });
+        std::vector<double> covered(sc.instance_count, 0.0);
+        for (uint32_t a = 0; a < sc.instance_count; ++a) {
+            box3 const& ba = instance_world[by_x[a]];
+            for (uint32_t b = a + 1; b < sc.instance_count; ++b) {
+                box3 const& bb = instance_world[by_x[b]];
+                if (bb.lo[0] > ba.hi[0]) {
+                    break;
+                }
+                box3 both;
+                bool empty = false;
+                for (int k = 0; k < 3; ++k) {
+                    both.lo[k] = std::max(ba.lo[k], bb.lo[k]);
+                    both.hi[k] = std::min(ba.hi[k], bb.hi[k]);
+                    empty = empty || both.lo[k] > both.hi[k];
+                }
+                if (!empty) {
+                    covered[by_x[a]] += both.half_area();
+                    covered[by_x[b]] += both.half_area();
+                }
+            }
+        }
+        for (uint32_t i = 0; i < sc.instance_count; ++i) {
+            crowded[i] = covered[i] >= (double) overlap_needed * instance_world[i].half_area() ? 1 : 0;
+            if (crowded[i]) {
+                crowded_triangles += sc.meshes[sc.instances[i].mesh].triangle_count;
+            }
+        }
+    }
+    // TLAS leaves to add by opening: one per kTrianglesPerOpenedEntry triangles of the crowded
+    // instances (staircase, 88 k triangles: 2 048 more leaves 214 Msamples/s, 8 192 more 229,
+    // 16 384 more 225, 65 536 more 208), within [kMinOpenedEntries, max_opened_entries].
+    uint32_t opened_entries = 0;
+    if (crowded_triangles > 0u) {
+        opened_entries = (uint32_t) std::min<uint64_t>(max_opened_entries,
+            std::max<uint64_t>(kMinOpenedEntries, crowded_triangles / kTrianglesPerOpenedEntry));
     }
 
     // The stack holds TLAS siblings + one marker + BLAS siblings.  The TLAS gets the levels a
@@ -734,48 +793,8 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t opened_entries) {
         e.instance = i;
         e.subtree = mesh_root[sc.instances[i].mesh];
         e.object_box = mesh_bounds[sc.instances[i].mesh];
-        e.world = world_box(sc, sc.instances[i], e.object_box);
+        e.world = instance_world[i];
         entries.push_back(e);
-    }
-    // Which instances stand among others: those whose box is covered kOpenOverlap times over
-    // (by surface area) by the boxes of the other instances.  A floor under a car or spheres
-    // on a plane are not; opening them only multiplies the instance records a ray has to enter.
-    char const* const gate = getenv("RT_HIP_OPEN_OVERLAP");  // tuning knob for experiments
-    float const overlap_needed = gate ? (float) atof(gate) : kOpenOverlap;
-    std::vector<char> crowded(sc.instance_count, 0);
-    if (opened_entries > 0u) {
-        // by x-sorted sweep: instances whose x ranges do not meet cannot overlap
-        std::vector<uint32_t> by_x(sc.instance_count);
-        for (uint32_t i = 0; i < sc.instance_count; ++i) {
-            by_x[i] = i;
-        }
-        std::sort(by_x.begin(), by_x.end(), [&](uint32_t a, uint32_t b) {
-            return entries[a].world.lo[0] < entries[b].world.lo[0];
-        });
-        std::vector<double> covered(sc.instance_count, 0.0);
-        for (uint32_t a = 0; a < sc.instance_count; ++a) {
-            box3 const& ba = entries[by_x[a]].world;
-            for (uint32_t b = a + 1; b < sc.instance_count; ++b) {
-                box3 const& bb = entries[by_x[b]].world;
-                if (bb.lo[0] > ba.hi[0]) {
-                    break;
-                }
-                box3 both;
-                bool empty = false;
-                for (int k = 0; k < 3; ++k) {
-                    both.lo[k] = std::max(ba.lo[k], bb.lo[k]);
-                    both.hi[k] = std::min(ba.hi[k], bb.hi[k]);
-                    empty = empty || both.lo[k] > both.hi[k];
-                }
-                if (!empty) {
-                    covered[by_x[a]] += both.half_area();
-                    covered[by_x[b]] += both.half_area();
-                }
-            }
-        }
-        for (uint32_t i = 0; i < sc.instance_count; ++i) {
-            crowded[i] = covered[i] >= (double) overlap_needed * entries[i].world.half_area() ? 1 : 0;
-        }
     }
     auto area_less = [&](uint32_t a, uint32_t b) {
         return entries[a].world.half_area() < entries[b].world.half_area();

@@ -18,14 +18,15 @@ struct built_accel {
     uint32_t max_stack_bound = 0;         // TLAS depth + 1 + deepest BLAS depth
 };
 
-// TLAS leaves added by opening instances (build_wide_accel splits the instances with the
-// largest world boxes into subtrees of their BLAS until this many more leaves exist).
-constexpr uint32_t kOpenedEntries = 2048;
+// Most TLAS leaves that opening instances may add (build_wide_accel splits the crowded
+// instances with the largest world boxes into subtrees of their BLAS; how many leaves it adds
+// depends on how many triangles those instances have).
+constexpr uint32_t kOpenedEntries = 16384;
 
 // Builds binned-SAH binary trees over the uploaded triangles (one BLAS per
 // mesh, shared by its instances) and over the world boxes of the instances
 // or, where instances were opened, of their parts.
 // Throws std::runtime_error on malformed input.
-built_accel build_wide_accel(rt_scene_desc const& scene, uint32_t opened_entries = kOpenedEntries);
+built_accel build_wide_accel(rt_scene_desc const& scene, uint32_t max_opened_entries = kOpenedEntries);
 
 }  // namespace rtd

@@ -57,19 +57,21 @@ def leaves_of(line):
 def test_instance_opening():
     """Instances that stand inside other instances' boxes are opened into subtrees of their
     BLAS (one TLAS leaf each); the checker verifies that the leaves of an instance still hold
-    each of its triangles exactly once.  With the default gate only the staircase interior
-    qualifies; with the gate at zero every scene is opened, up to the budget or until only
-    single BLAS leaves are left."""
+    each of its triangles.  With the default gate only the staircase interior qualifies; with
+    the gate at zero every scene is opened, up to its budget (one leaf per ten triangles of
+    the opened instances, between 2 048 and 16 384) or until only single BLAS leaves are left."""
     names = ["cornell_box", "hyperion_rect_light", "mustang_red_reduced", "staircase_reduced",
              "teapot_standin"]
     paths = [scenes.snapshot_path(n) for n in names]
     default = dict(zip(names, map(leaves_of, run_tool(paths))))
+    # the staircase's 19 crowded instances hold 88 431 of its 88 433 triangles
     assert default == {"cornell_box": 8, "hyperion_rect_light": 28, "mustang_red_reduced": 5,
-                       "staircase_reduced": 20 + 2048, "teapot_standin": 2}
+                       "staircase_reduced": 20 + 8843, "teapot_standin": 2}
     opened = run_tool(paths, env={"RT_HIP_OPEN_OVERLAP": "0"})
     every = dict(zip(names, map(leaves_of, opened)))
     assert every["cornell_box"] == 18          # 36 triangles in leaves of two
-    assert every["hyperion_rect_light"] == 28 + 2048 and every["teapot_standin"] == 2 + 2048
+    assert 28 + 10000 < every["hyperion_rect_light"] < 28 + 12000   # a tenth of 107 k triangles
+    assert every["teapot_standin"] == 2 + 2048
     for line in opened:
         assert 1 <= int(line.split("stack bound ")[1].split()[0]) <= 40, line
 
