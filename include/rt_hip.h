@@ -8,7 +8,11 @@
  * Only plain pointers, sizes and PODs cross it; every function returns 0 on
  * success and a non-zero code on failure, with rt_hip_last_error() holding a
  * message for the calling thread.  A renderer handle is used from one host
- * thread at a time (the reference's callbacks are never re-entered).
+ * thread at a time (the reference's callbacks are never re-entered), and its
+ * calls are ordered on the device: a call on another stream than the handle's
+ * previous call first waits for that call's work, because every call shares
+ * the handle's path state and counters.  Calls leave the calling thread's
+ * current HIP device as they found it.
  *
  * Buffers named *_dev are device pointers on the renderer's GPU; everything
  * else is host memory that the call has finished reading when it returns.
@@ -171,6 +175,24 @@ int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
  * alive in bounce `trip` (counts[0]) and how many closest-hit (counts[1]) and occlusion
  * (counts[2]) rays it traced.  Synchronises the device.  No counterpart in the reference. */
 int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts);
+
+/* Diagnostics of the pipeline with RT_HIP_FLAG_COUNT_NODES and the rebuilt acceleration
+ * structure: what the traversal fetched since the statistics were last reset, and how it was
+ * served.  nodes / tris repeat rt_stats.nodes_visited / tris_tested; the trace launches read
+ * nodes_from_lds of the nodes and instance_records_from_lds of the instance records from the
+ * workgroup's LDS copy of the most visited ones (node_bytes_cached of node_bytes), the rest
+ * through the cache hierarchy; finish_* is the share of the kernel that runs the last few
+ * paths of a batch to their end.  *_bytes: size of the structure as traversed (the reference
+ * layout in RT_HIP_ACCEL_REFERENCE mode).  Synchronises the device.  No counterpart in the
+ * reference. */
+typedef struct rt_hip_trace_work_counts {
+    uint64_t nodes, tris;
+    uint64_t nodes_from_lds;
+    uint64_t instance_records, instance_records_from_lds;
+    uint64_t finish_nodes, finish_tris;
+    uint64_t node_bytes, node_bytes_cached, triangle_bytes, instance_bytes;
+} rt_hip_trace_work_counts;
+int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out);
 
 /* Diagnostics of the pipeline: whether ray binning is in use for the uploaded scene
  * (RT_HIP_BINNING_*: ON = for at least one bounce) and, when it was decided by measurement,

@@ -289,6 +289,36 @@ __global__ void clear_rgba_kernel(float4* img, size_t count) {
 
 thread_local std::string g_last_error;
 
+// Makes `device` current for the duration of one C ABI call and puts the caller's device
+// back afterwards (a caller that also drives PyTorch or another renderer must not find its
+// current device changed).
+class device_scope {
+public:
+    explicit device_scope(int device) {
+        if (hipGetDevice(&previous_) != hipSuccess) {
+            previous_ = -1;
+        }
+        if (previous_ != device) {
+            hipError_t const e = hipSetDevice(device);
+            if (e != hipSuccess) {
+                throw std::runtime_error(std::string{"hipSetDevice: "} + hipGetErrorString(e));
+            }
+            changed_ = true;
+        }
+    }
+    ~device_scope() {
+        if (changed_ && previous_ >= 0) {
+            (void) hipSetDevice(previous_);
+        }
+    }
+    device_scope(device_scope const&) = delete;
+    device_scope& operator=(device_scope const&) = delete;
+
+private:
+    int previous_ = -1;
+    bool changed_ = false;
+};
+
 struct hip_failure : std::runtime_error {
     using std::runtime_error::runtime_error;
 };
@@ -338,6 +368,7 @@ struct rt_hip_renderer {
     std::vector<void*> scene_allocs;
     scene_dev sc{};
     bool scene_ready = false;
+    uint64_t accel_node_bytes = 0, accel_tri_bytes = 0, accel_instance_bytes = 0;  // as traversed
 
     uint32_t* seeds = nullptr;
     size_t seeds_capacity = 0;
@@ -353,6 +384,7 @@ struct rt_hip_renderer {
     uint32_t wf_trips = 0;
     uint32_t wf_extend_grid = 0, wf_extend_waves = 0, wf_shade_grid = 0;  // workgroups, waves
     uint32_t wf_finish_grid = 0;
+    uint32_t wf_stat_waves = 0;       // slots of wf.wave_stats
     uint32_t wf_bin_groups = 0;       // workgroups of the ray binning launches
     bool wf_binned = false;           // the binning buffers exist
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};  // world bounds of the scene
@@ -378,7 +410,23 @@ struct rt_hip_renderer {
     double seconds_total[3] = {0.0, 0.0, 0.0};  // per RT_HIP_KERNEL_*
     uint32_t launches_total[3] = {0, 0, 0};
 
-    void use_device() const { HIP_CHECK(hipSetDevice(device)); }
+    // One handle is driven through one stream at a time: a call on another stream than the
+    // previous one first waits (on the device) for that call's work, because all calls share
+    // the handle's path state, queues and counters.
+    hipEvent_t last_done = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool last_recorded = false;
+
+    void follow(hipStream_t stream) {
+        if (last_recorded && stream != last_stream) {
+            HIP_CHECK(hipStreamWaitEvent(stream, last_done, 0));
+        }
+    }
+    void mark(hipStream_t stream) {
+        HIP_CHECK(hipEventRecord(last_done, stream));
+        last_stream = stream;
+        last_recorded = true;
+    }
 
     template <typename T>
     T* upload(T const* host, size_t count) {
@@ -627,49 +675,54 @@ void settle_binning_probe(rt_hip_renderer& r) {
     r.binning = any ? RT_HIP_BINNING_ON : RT_HIP_BINNING_OFF;
 }
 
-void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool binned) {
-    if (r.wf_extend_grid == 0) {
-        hipDeviceProp_t prop{};
-        HIP_CHECK(hipGetDeviceProperties(&prop, r.device));
-        uint32_t const cus = (uint32_t) std::max(1, prop.multiProcessorCount);
-        auto resident = [&](auto kernel) {
-            int per_cu = 0;
-            HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0));
-            return cus * (uint32_t) std::max(1, per_cu);
+// Launch geometry of the pipeline's kernels on this renderer's device, their LDS allowances
+// and the per-wave work counters: set up once, when the renderer is created, so that no render
+// call has to (the allocation-free entry point may not).
+void init_launch_plan(rt_hip_renderer& r) {
+    hipDeviceProp_t prop{};
+    HIP_CHECK(hipGetDeviceProperties(&prop, r.device));
+    uint32_t const cus = (uint32_t) std::max(1, prop.multiProcessorCount);
+    auto resident = [&](auto kernel) {
+        int per_cu = 0;
+        HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, 0));
+        return cus * (uint32_t) std::max(1, per_cu);
+    };
+    bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
+    if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
+        r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true, false>)
+                                 : resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false, false>);
+        r.wf_extend_waves = r.wf_extend_grid;
+    } else {
+        // one workgroup per CU: it takes (nearly) all of the CU's LDS
+        r.wf_extend_grid = cus;
+        r.wf_extend_waves = cus * (kExtendThreads / 64u);
+        auto allow = [&](auto kernel) {
+            HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                hipFuncAttributeMaxDynamicSharedMemorySize, (int) kLdsBytesPerCu));
         };
-        bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
-        if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
-            r.wf_extend_grid = count ? resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, true, false>)
-                                     : resident(wf_extend_kernel<RT_HIP_ACCEL_REFERENCE, false, false>);
-            r.wf_extend_waves = r.wf_extend_grid;
-        } else {
-            // one workgroup per CU: it takes (nearly) all of the CU's LDS
-            r.wf_extend_grid = cus;
-            r.wf_extend_waves = cus * (kExtendThreads / 64u);
-            auto allow = [&](auto kernel) {
-                HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int) kLdsBytesPerCu));
-            };
-            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, false>);
-            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, false>);
-            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, true>);
-            allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, true>);
-        }
-        // two workgroups of four waves per CU (the kernel's registers allow two waves per
-        // SIMD), each with its own LDS copy of the scene's small tables
-        r.wf_shade_grid = cus * 2u;
-        r.wf_finish_grid = cus * 8u;  // one-wave workgroups, two per SIMD
-        r.wf_bin_groups = cus;
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_count_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
-        HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_place_kernel),
-            hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
-        // per-wave work counters: allocated once, they outlive a regrowth of the state arrays
-        size_t const stat_bytes = (size_t) std::max({r.wf_extend_waves, r.wf_shade_grid * (kShadeThreads / 64u), r.wf_finish_grid}) *
-                                  kStatWords * sizeof(unsigned long long);
-        HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
-        HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
+        allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, false>);
+        allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, false>);
+        allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, true, true>);
+        allow(wf_extend_kernel<RT_HIP_ACCEL_REBUILT, false, true>);
     }
+    // two workgroups of four waves per CU (the kernel's registers allow two waves per
+    // SIMD), each with its own LDS copy of the scene's small tables
+    r.wf_shade_grid = cus * 2u;
+    r.wf_finish_grid = cus * 8u;  // one-wave workgroups, two per SIMD
+    r.wf_bin_groups = cus;
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_count_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
+    HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_place_kernel),
+        hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
+    // per-wave work counters: they outlive every regrowth of the state arrays
+    r.wf_stat_waves = std::max({r.wf_extend_waves, r.wf_shade_grid * (kShadeThreads / 64u),
+        r.wf_finish_grid});
+    size_t const stat_bytes = (size_t) r.wf_stat_waves * kStatWords * sizeof(unsigned long long);
+    HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
+    HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
+}
+
+void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool binned) {
     auto alloc = [&](size_t bytes) {
         void* d = nullptr;
         HIP_CHECK(hipMalloc(&d, bytes));
@@ -724,28 +777,42 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
 }
 
 // rt_hip_render through the wavefront pipeline (rt_wavefront.h).
-void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t stream) {
+//
+// `fixed` = nullptr: the pipeline state lives in the renderer's own device allocations, grown on
+// demand (ensure_wavefront).  Otherwise `fixed` describes state arrays for `fixed_paths` paths
+// that already exist (the allocation-free entry point): nothing is allocated, created or timed,
+// the ray queues are never regrouped, and a rectangle that does not fit is refused.
+void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t stream,
+    const wavefront_params* fixed = nullptr, size_t fixed_paths = 0) {
     uint32_t const blocks_x = (p.x1 - p.x0 + 7u) / 8u;
     uint32_t const blocks_y = (p.y1 - p.y0 + 7u) / 8u;
     size_t const per_pass = (size_t) blocks_x * blocks_y * 64u;
-    if (per_pass > kLivePidMask) {
-        throw std::runtime_error("render: rectangle too large for one batch");
-    }
     static_assert(kWavefrontMaxPaths / 64u / kTileChunks <= kScanThreads,
         "one workgroup must be able to scan the tile sums");
-    size_t const limit = std::min(kWavefrontMaxPaths, (size_t) kLivePidMask + 1u);
+    static_assert(kWavefrontMaxPaths <= (size_t) kLivePidMask + 1u, "a pid must fit a list entry");
+    size_t const limit = fixed ? fixed_paths : kWavefrontMaxPaths;
+    if (per_pass > limit) {
+        // one pass of the rectangle is the smallest batch; the compaction (one workgroup scans
+        // the tile sums) and the state arrays are sized for `limit` paths
+        throw std::runtime_error("render: one pass of the rectangle is " +
+                                 std::to_string(per_pass) + " paths, more than the " +
+                                 std::to_string(limit) +
+                                 " one batch can hold; render it as smaller rectangles");
+    }
     uint32_t const batch =
         (uint32_t) std::min<size_t>(p.pass_count, std::max<size_t>(1, limit / per_pass));
     uint32_t const trips = p.max_depth + 1u;
-    settle_binning_probe(r);
-    bool const binned = r.binning == RT_HIP_BINNING_ON;
+    if (!fixed) {
+        settle_binning_probe(r);
+    }
+    bool const binned = !fixed && r.binning == RT_HIP_BINNING_ON;
     // trips beyond those measured (a forced ON has measured none) are binned
     auto trip_binned = [&](uint32_t trip) {
         return binned && trip >= 1u && (trip >= r.bin_trip.size() || r.bin_trip[trip] != 0);
     };
     // measure this call?  (one batch is enough; a probe in flight is left alone)
-    bool probe = r.binning == RT_HIP_BINNING_UNDECIDED && !r.probe_pending && trips > 1u &&
-                 per_pass * batch >= kProbeMinPaths;
+    bool probe = !fixed && r.binning == RT_HIP_BINNING_UNDECIDED && !r.probe_pending &&
+                 trips > 1u && per_pass * batch >= kProbeMinPaths;
     if (probe) {
         while (r.probe_events.size() < 2u * trips) {
             hipEvent_t e = nullptr;
@@ -761,9 +828,11 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
             r.probe_counts_trips = trips;
         }
     }
-    ensure_wavefront(r, per_pass * batch, trips, binned);
+    if (!fixed) {
+        ensure_wavefront(r, per_pass * batch, trips, binned);
+    }
 
-    wavefront_params w = r.wf;
+    wavefront_params w = fixed ? *fixed : r.wf;
     w.sort_rays = 0u;  // set per trip below
     {
         // the grid of origin cells: kBinCellBits halvings, each of the axis whose cells are
@@ -810,7 +879,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     w.preview = p.preview;
     w.counters = p.counters;
     bool const count = (r.cfg.flags & RT_HIP_FLAG_COUNT_NODES) != 0;
-    bool const each = (r.cfg.flags & RT_HIP_FLAG_TIME_KERNELS) != 0;
+    bool const each = !fixed && (r.cfg.flags & RT_HIP_FLAG_TIME_KERNELS) != 0;
 
     uint32_t const extend_lds =
         w.sc.cached_nodes * (uint32_t) sizeof(wide_node) + w.sc.cached_instances * 64u +
@@ -899,7 +968,10 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         }
     };
 
-    auto whole = r.begin_timing(stream);
+    rt_hip_renderer::timed_launch whole{};
+    if (!fixed) {
+        whole = r.begin_timing(stream);
+    }
     for (uint32_t first = 0; first < p.pass_count; first += batch) {
         w.pass_count = std::min(batch, p.pass_count - first);
         w.seeds = p.seeds ? p.seeds + (size_t) first * p.tile_count : nullptr;
@@ -963,7 +1035,9 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
             dim3(256), 0, stream, w);
         HIP_CHECK(hipGetLastError());
     }
-    r.end_timing(whole, stream);
+    if (!fixed) {
+        r.end_timing(whole, stream);
+    }
 }
 
 render_params base_params(rt_hip_renderer const& r, rt_camera const& cam) {
@@ -992,6 +1066,55 @@ void require_scene(rt_hip_renderer const* r) {
     }
     if (!r->scene_ready) {
         throw std::runtime_error("no scene uploaded");
+    }
+}
+
+}  // namespace
+
+namespace {
+
+void render_passes(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
+    uint32_t pass_count, const uint32_t* rect, float* accum_dev, hipStream_t stream,
+    bool allocation_free) {
+    require_scene(r);
+    if (!camera) {
+        throw std::runtime_error("render: null camera");
+    }
+    if (pass_count == 0) {
+        return;
+    }
+    if (!r->seeds || first_pass < r->seeds_first_pass ||
+        (uint64_t) first_pass + pass_count > (uint64_t) r->seeds_first_pass + r->seeds_pass_count) {
+        throw std::runtime_error("render: seeds for the requested passes are not resident");
+    }
+    device_scope const on_device(r->device);
+    render_params p = base_params(*r, *camera);
+    if (rect) {
+        if (rect[0] >= rect[2] || rect[1] >= rect[3] || rect[2] > r->cfg.width ||
+            rect[3] > r->cfg.height) {
+            throw std::runtime_error("render: bad rectangle");
+        }
+        p.x0 = rect[0];
+        p.y0 = rect[1];
+        p.x1 = rect[2];
+        p.y1 = rect[3];
+    }
+    if (accum_dev) {
+        p.accum = accum_dev;
+    }
+    p.pass_count = pass_count;
+    p.seeds = r->seeds + (size_t) (first_pass - r->seeds_first_pass) * p.tile_count;
+    r->follow(stream);
+    if (allocation_free) {
+        throw std::logic_error("no allocation-free path in this build");
+    } else if (r->cfg.flags & RT_HIP_FLAG_FUSED) {
+        launch_path_trace(*r, p, stream);
+    } else {
+        launch_wavefront(*r, p, stream);
+    }
+    r->mark(stream);
+    if (!accum_dev && !rect) {
+        r->passes_done += pass_count;
     }
 }
 
@@ -1035,7 +1158,7 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         if (r->device >= device_count) {
             throw std::runtime_error("create: device ordinal out of range");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         r->tiles_x = c.width / c.tile_width;
         r->tiles_y = c.height / c.tile_height;
         r->preview_w = std::max(1u, c.width / kPreviewRatio);
@@ -1053,6 +1176,8 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         HIP_CHECK(hipMalloc((void**) &r->block_order, r->block_total * sizeof(uint32_t)));
         HIP_CHECK(hipMemset(r->block_cost, 0, r->block_total * sizeof(uint32_t)));
         HIP_CHECK(hipEventCreate(&r->probe_done));
+        HIP_CHECK(hipEventCreateWithFlags(&r->last_done, hipEventDisableTiming));
+        init_launch_plan(*r);
         *out = r.release();
     });
 }
@@ -1064,7 +1189,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         }
         validate_scene(*scene);
         rt_scene_desc const& s = *scene;
-        r->use_device();
+        device_scope const on_device(r->device);
         HIP_CHECK(hipDeviceSynchronize());
         r->free_scene();
         scene_dev d{};
@@ -1100,6 +1225,10 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             for (uint32_t m = 0; m < s.mesh_count; ++m) {
                 blas_depth = std::max(blas_depth, ref_depth(s.blas, s.meshes[m].bvh_start));
             }
+            r->accel_node_bytes = ((uint64_t) s.tlas_count + s.blas_count) * sizeof(rt_bvh_node);
+            r->accel_tri_bytes = (uint64_t) s.triangle_count * sizeof(rt_triangle);
+            r->accel_instance_bytes = (uint64_t) s.instance_count * sizeof(rt_instance) +
+                                      (uint64_t) s.transform_count * sizeof(rt_mat4);
             uint32_t const need = ref_depth(s.tlas, 0) + blas_depth;
             if (need > kRefStackCapacity) {
                 throw std::runtime_error("upload_scene: the uploaded BVH is " +
@@ -1119,6 +1248,9 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             d.wide_tris = r->upload(accel.tris.data(), accel.tris.size());
             d.wide_instances = r->upload(accel.instances.data(), accel.instances.size());
             d.wide_tlas_root = accel.tlas_root;
+            r->accel_node_bytes = accel.nodes.size() * sizeof(wide_node);
+            r->accel_tri_bytes = accel.tris.size() * sizeof(tri_pos);
+            r->accel_instance_bytes = accel.instances.size() * sizeof(instance_rec);
             // LDS plan of the cached traversal kernel (wf_extend_kernel): stacks first, the
             // rest goes to the instance records (at most half) and the hottest nodes.
             d.stack_entries = std::max(1u, accel.max_stack_bound);
@@ -1162,7 +1294,7 @@ int rt_hip_upload_seeds(rt_hip_renderer* r, const uint32_t* seeds, uint32_t firs
         if (!r || !seeds || pass_count == 0) {
             throw std::runtime_error("upload_seeds: null or empty argument");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         size_t const words = (size_t) pass_count * r->tiles_x * r->tiles_y;
         HIP_CHECK(hipDeviceSynchronize());
         if (words > r->seeds_capacity) {
@@ -1185,12 +1317,14 @@ int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream) {
         if (!r) {
             throw std::runtime_error("null renderer");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         size_t const pixels = (size_t) r->cfg.width * r->cfg.height;
         float* target = accum_dev ? accum_dev : r->accum;
+        r->follow((hipStream_t) stream);
         hipLaunchKernelGGL(clear_rgba_kernel, dim3((uint32_t) ((pixels + 255) / 256)), dim3(256),
             0, (hipStream_t) stream, reinterpret_cast<float4*>(target), pixels);
         HIP_CHECK(hipGetLastError());
+        r->mark((hipStream_t) stream);
         if (!accum_dev) {
             r->passes_done = 0;
             r->tile_cursor = 0;
@@ -1201,43 +1335,8 @@ int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream) {
 int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
     uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream) {
     return guarded([&] {
-        require_scene(r);
-        if (!camera) {
-            throw std::runtime_error("render: null camera");
-        }
-        if (pass_count == 0) {
-            return;
-        }
-        if (!r->seeds || first_pass < r->seeds_first_pass ||
-            (uint64_t) first_pass + pass_count >
-                (uint64_t) r->seeds_first_pass + r->seeds_pass_count) {
-            throw std::runtime_error("render: seeds for the requested passes are not resident");
-        }
-        r->use_device();
-        render_params p = base_params(*r, *camera);
-        if (rect) {
-            if (rect[0] >= rect[2] || rect[1] >= rect[3] || rect[2] > r->cfg.width ||
-                rect[3] > r->cfg.height) {
-                throw std::runtime_error("render: bad rectangle");
-            }
-            p.x0 = rect[0];
-            p.y0 = rect[1];
-            p.x1 = rect[2];
-            p.y1 = rect[3];
-        }
-        if (accum_dev) {
-            p.accum = accum_dev;
-        }
-        p.pass_count = pass_count;
-        p.seeds = r->seeds + (size_t) (first_pass - r->seeds_first_pass) * p.tile_count;
-        if (r->cfg.flags & RT_HIP_FLAG_FUSED) {
-            launch_path_trace(*r, p, (hipStream_t) stream);
-        } else {
-            launch_wavefront(*r, p, (hipStream_t) stream);
-        }
-        if (!accum_dev && !rect) {
-            r->passes_done += pass_count;
-        }
+        render_passes(r, camera, first_pass, pass_count, rect, accum_dev, (hipStream_t) stream,
+            false);
     });
 }
 
@@ -1251,7 +1350,7 @@ int rt_hip_render_tile(rt_hip_renderer* r, const rt_camera* camera, uint32_t ran
         if (tile_x >= r->tiles_x || tile_y >= r->tiles_y) {
             throw std::runtime_error("render_tile: tile index out of range");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         render_params p = base_params(*r, *camera);
         p.x0 = tile_x * r->cfg.tile_width;
         p.y0 = tile_y * r->cfg.tile_height;
@@ -1259,7 +1358,9 @@ int rt_hip_render_tile(rt_hip_renderer* r, const rt_camera* camera, uint32_t ran
         p.y1 = p.y0 + r->cfg.tile_height;
         p.seeds = nullptr;
         p.scalar_seed = random_seed;
+        r->follow((hipStream_t) stream);
         launch_path_trace(*r, p, (hipStream_t) stream);
+        r->mark((hipStream_t) stream);
         if (++r->tile_cursor == r->tiles_x * r->tiles_y) {
             r->tile_cursor = 0;
             ++r->passes_done;
@@ -1274,7 +1375,7 @@ int rt_hip_render_preview(rt_hip_renderer* r, const rt_camera* preview_camera,
         if (!preview_camera) {
             throw std::runtime_error("render_preview: null camera");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         render_params p = base_params(*r, *preview_camera);
         p.accum = r->preview;
         p.frame_width = r->preview_w;
@@ -1283,7 +1384,9 @@ int rt_hip_render_preview(rt_hip_renderer* r, const rt_camera* preview_camera,
         p.preview = 1;
         p.seeds = nullptr;
         p.scalar_seed = random_seed;
+        r->follow((hipStream_t) stream);
         launch_path_trace(*r, p, (hipStream_t) stream);
+        r->mark((hipStream_t) stream);
         r->passes_done = 0;
         r->tile_cursor = 0;
     });
@@ -1300,7 +1403,7 @@ int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pas
             pass >= r->seeds_first_pass + r->seeds_pass_count) {
             throw std::runtime_error("primary_ids: seeds for that pass are not resident");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         size_t const pixels = (size_t) r->cfg.width * r->cfg.height;
         render_params p = base_params(*r, *camera);
         p.seeds = r->seeds + (size_t) (pass - r->seeds_first_pass) * p.tile_count;
@@ -1352,7 +1455,7 @@ int rt_hip_read_accum(rt_hip_renderer* r, float* rgba, uint32_t* passes, void* s
         if (!r || !rgba) {
             throw std::runtime_error("read_accum: null argument");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         HIP_CHECK(hipStreamSynchronize((hipStream_t) stream));
         HIP_CHECK(hipMemcpy(rgba, r->accum, (size_t) r->cfg.width * r->cfg.height * 16,
             hipMemcpyDeviceToHost));
@@ -1367,7 +1470,7 @@ int rt_hip_read_preview(rt_hip_renderer* r, float* rgba, void* stream) {
         if (!r || !rgba) {
             throw std::runtime_error("read_preview: null argument");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         HIP_CHECK(hipStreamSynchronize((hipStream_t) stream));
         HIP_CHECK(hipMemcpy(rgba, r->preview, (size_t) r->preview_w * r->preview_h * 16,
             hipMemcpyDeviceToHost));
@@ -1406,16 +1509,14 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
         if (!r) {
             throw std::runtime_error("null renderer");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         HIP_CHECK(hipDeviceSynchronize());
         r->fold_timings();
         unsigned long long words[kCounterWords];
         HIP_CHECK(hipMemcpy(words, r->counters, sizeof(words), hipMemcpyDeviceToHost));
         if (r->wf.wave_stats != nullptr) {
             // the pipeline keeps its work counters per wave
-            size_t const waves =
-                std::max({r->wf_extend_waves, r->wf_shade_grid * (kShadeThreads / 64u),
-                    r->wf_finish_grid});
+            size_t const waves = r->wf_stat_waves;
             std::vector<unsigned long long> per_wave(waves * kStatWords);
             HIP_CHECK(hipMemcpy(per_wave.data(), r->wf.wave_stats,
                 per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -1471,7 +1572,7 @@ int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
         if (kernel > RT_HIP_KERNEL_SHADE) {
             throw std::runtime_error("kernel_time_of: unknown kernel");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         r->fold_timings();
         if (avg_ms) {
             *avg_ms = r->launches_total[kernel]
@@ -1492,7 +1593,7 @@ int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts) {
         if (r->wf_allocs.empty() || trip >= r->wf_trips) {
             throw std::runtime_error("trip_counts: no pipeline batch has run that many trips");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         HIP_CHECK(hipDeviceSynchronize());
         uint32_t words[kCtlWords];
         HIP_CHECK(hipMemcpy(words, r->wf.control + (size_t) trip * kCtlWords, sizeof(words),
@@ -1500,6 +1601,37 @@ int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts) {
         counts[0] = words[kCtlLive];
         counts[1] = words[kCtlClosest];
         counts[2] = words[kCtlShadow];
+    });
+}
+
+int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out) {
+    return guarded([&] {
+        if (!r || !out) {
+            throw std::runtime_error("trace_work: null argument");
+        }
+        device_scope const on_device(r->device);
+        HIP_CHECK(hipDeviceSynchronize());
+        *out = rt_hip_trace_work_counts{};
+        if (r->wf.wave_stats == nullptr) {
+            return;
+        }
+        std::vector<unsigned long long> per_wave((size_t) r->wf_stat_waves * kStatWords);
+        HIP_CHECK(hipMemcpy(per_wave.data(), r->wf.wave_stats,
+            per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (size_t wv = 0; wv < r->wf_stat_waves; ++wv) {
+            unsigned long long const* s = &per_wave[wv * kStatWords];
+            out->nodes += s[kStatNodes];
+            out->tris += s[kStatTris];
+            out->nodes_from_lds += s[kStatLdsNodes];
+            out->instance_records += s[kStatInstances];
+            out->instance_records_from_lds += s[kStatLdsInstances];
+            out->finish_nodes += s[kStatFinishNodes];
+            out->finish_tris += s[kStatFinishTris];
+        }
+        out->node_bytes_cached = (uint64_t) r->sc.cached_nodes * sizeof(wide_node);
+        out->node_bytes = r->accel_node_bytes;
+        out->triangle_bytes = r->accel_tri_bytes;
+        out->instance_bytes = r->accel_instance_bytes;
     });
 }
 
@@ -1512,7 +1644,7 @@ int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per
         if (!r || !state || !probe_ns_per_ray) {
             throw std::runtime_error("ray_binning: null argument");
         }
-        r->use_device();
+        device_scope const on_device(r->device);
         settle_binning_probe(*r);
         *state = r->binning;
         *probe_ns_per_ray = r->probe_ns_per_ray;
@@ -1524,7 +1656,7 @@ int rt_hip_destroy(rt_hip_renderer* r) {
         if (!r) {
             return;
         }
-        (void) hipSetDevice(r->device);
+        device_scope const on_device(r->device);
         (void) hipDeviceSynchronize();
         r->free_scene();
         r->free_wavefront();
@@ -1541,6 +1673,7 @@ int rt_hip_destroy(rt_hip_renderer* r) {
             (void) hipEventDestroy(e);
         }
         (void) hipEventDestroy(r->probe_done);
+        (void) hipEventDestroy(r->last_done);
         if (r->probe_counts) {
             (void) hipHostFree(r->probe_counts);
         }

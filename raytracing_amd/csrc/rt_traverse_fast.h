@@ -203,6 +203,9 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 } else {
                     r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
                 }
+                if (COUNT) {
+                    ++cnt.instances;
+                }
                 // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
                 f3 o, d;
                 o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
@@ -284,6 +287,9 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         if (CACHED && (uint32_t) cur < stk.cached_nodes) {
             const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
             lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
+            if (COUNT) {
+                ++cnt.lds_nodes;
+            }
         } else {
             const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
             lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
@@ -356,8 +362,14 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             if (CACHED && rec_index < stk.cached_instances) {
                 const float4* lp = stk.instance_cache + 4u * rec_index;
                 r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+                if (COUNT) {
+                    ++cnt.lds_instances;
+                }
             } else {
                 r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
+            }
+            if (COUNT) {
+                ++cnt.instances;
             }
             // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
             f3 o, d;

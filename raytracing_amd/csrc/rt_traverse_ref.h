@@ -27,6 +27,10 @@ struct trace_counters {
     uint32_t nodes = 0;
     uint32_t tris = 0;
     uint32_t max_stack = 0;
+    // rebuilt structure only: how the fetches were served
+    uint32_t lds_nodes = 0;      // of `nodes`: read from the workgroup's LDS copy
+    uint32_t instances = 0;      // instance records fetched (TLAS leaves entered)
+    uint32_t lds_instances = 0;  // of `instances`: read from LDS
 };
 
 constexpr uint32_t kRefStackCapacity = 160;

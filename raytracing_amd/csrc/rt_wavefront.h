@@ -56,7 +56,13 @@ enum : uint32_t {
     kStatNodes = 3,
     kStatTris = 4,
     kStatMaxStack = 5,
-    kStatWords = 8,
+    // how the rebuilt structure's fetches were served (counted with RT_HIP_FLAG_COUNT_NODES)
+    kStatLdsNodes = 8,       // of kStatNodes: read from LDS by the trace launches
+    kStatInstances = 9,      // instance records fetched
+    kStatLdsInstances = 10,  // of those: read from LDS by the trace launches
+    kStatFinishNodes = 11,   // of kStatNodes / kStatTris: the finishing kernel's share
+    kStatFinishTris = 12,
+    kStatWords = 16,
 };
 constexpr uint32_t kScanThreads = 1024;
 
@@ -669,9 +675,15 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         for (int offset = 32; offset > 0; offset >>= 1) {
             deepest = max(deepest, (uint32_t) __shfl_down((int) deepest, offset, 64));
         }
+        unsigned long long const lds_nodes = wave_sum(cnt.lds_nodes);
+        unsigned long long const instances = wave_sum(cnt.instances);
+        unsigned long long const lds_instances = wave_sum(cnt.lds_instances);
         if (wave_lane() == 0) {
             add_wave_stat(p, kStatNodes, nodes);
             add_wave_stat(p, kStatTris, tris);
+            add_wave_stat(p, kStatLdsNodes, lds_nodes);
+            add_wave_stat(p, kStatInstances, instances);
+            add_wave_stat(p, kStatLdsInstances, lds_instances);
             unsigned long long* const slot =
                 p.wave_stats + (size_t) wave_index() * kStatWords + kStatMaxStack;
             *slot = max(*slot, (unsigned long long) deepest);
@@ -899,6 +911,7 @@ __global__ void __launch_bounds__(64, 2) wf_finish_kernel(wavefront_params const
         wave_sum(closest_hits), wave_sum(shadow_skipped)};
     unsigned long long const nodes = COUNT ? wave_sum(cnt.nodes) : 0ull;
     unsigned long long const tris = COUNT ? wave_sum(cnt.tris) : 0ull;
+    unsigned long long const instances = COUNT ? wave_sum(cnt.instances) : 0ull;
     uint32_t deepest = cnt.max_stack;
     for (int offset = 32; offset > 0; offset >>= 1) {
         deepest = max(deepest, (uint32_t) __shfl_down((int) deepest, offset, 64));
@@ -911,6 +924,9 @@ __global__ void __launch_bounds__(64, 2) wf_finish_kernel(wavefront_params const
         if (COUNT) {
             add_wave_stat(p, kStatNodes, nodes);
             add_wave_stat(p, kStatTris, tris);
+            add_wave_stat(p, kStatFinishNodes, nodes);
+            add_wave_stat(p, kStatFinishTris, tris);
+            add_wave_stat(p, kStatInstances, instances);
             unsigned long long* const slot =
                 p.wave_stats + (size_t) wave_index() * kStatWords + kStatMaxStack;
             *slot = max(*slot, (unsigned long long) deepest);

@@ -29,11 +29,13 @@ def reduce_accumulator(accum, dst=0, group=None):
 
     The alpha channel of every accumulator is 1 (the shader writes vec4(colour, 1)); after the
     sum it is reset to 1 on the destination so the image keeps the reference's convention.
+    `dst` is a GLOBAL rank, as torch.distributed.reduce takes it, also when `group` is a
+    sub-group.
     """
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return accum
     dist.reduce(accum, dst=dst, op=dist.ReduceOp.SUM, group=group)
-    if dist.get_rank(group) == dst:
+    if dist.get_rank() == dst:
         accum[..., 3] = 1.0
     return accum
 

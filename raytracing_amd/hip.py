@@ -31,7 +31,7 @@ EXPORTS = [
     "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
-    "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
+    "rt_hip_trace_work", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
 
@@ -39,6 +39,13 @@ class Config(C.Structure):
     _fields_ = [("width", C.c_uint32), ("height", C.c_uint32), ("max_depth", C.c_uint32),
                 ("tile_width", C.c_uint32), ("tile_height", C.c_uint32), ("device", C.c_int32),
                 ("accel", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class TraceWork(C.Structure):
+    _fields_ = [(name, C.c_uint64) for name in (
+        "nodes", "tris", "nodes_from_lds", "instance_records", "instance_records_from_lds",
+        "finish_nodes", "finish_tris", "node_bytes", "node_bytes_cached", "triangle_bytes",
+        "instance_bytes")]
 
 
 fp = C.POINTER(C.c_float)
@@ -81,6 +88,8 @@ def lib():
         l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
         l.rt_hip_kernel_time_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), u32p]
         l.rt_hip_trip_counts.argtypes = [C.c_void_p, C.c_uint32, u32p]
+        l.rt_hip_trace_work.argtypes = [C.c_void_p, C.POINTER(TraceWork)]
+        l.rt_hip_ray_binning.argtypes = [C.c_void_p, u32p, C.POINTER(C.c_double)]
         l.rt_hip_destroy.argtypes = [C.c_void_p]
         _lib = l
     return _lib
@@ -177,6 +186,12 @@ class HipRenderer:
         ns = C.c_double()
         _check(lib().rt_hip_ray_binning(self._h, C.byref(state), C.byref(ns)))
         return state.value, ns.value
+
+    def trace_work(self):
+        """What the traversal fetched and how it was served (needs FLAG_COUNT_NODES)."""
+        out = TraceWork()
+        _check(lib().rt_hip_trace_work(self._h, C.byref(out)))
+        return {name: getattr(out, name) for name, _ in out._fields_}
 
     def trip_counts(self, trip):
         """(live paths, closest-hit rays, occlusion rays) of bounce `trip` in the last batch."""
