@@ -120,6 +120,22 @@ int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream);
 int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
     uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream);
 
+/* rt_hip_render for callers that cannot allocate device memory while they render: code under
+ * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in
+ * the reference.  Same arguments, same result bit for bit, but the call allocates nothing,
+ * creates no events and records no timings: the pipeline's path state and queues live in a
+ * fixed device array inside the library (about 41 MB per GPU the library runs on, held until
+ * the process ends) that holds RT_HIP_NOALLOC_MAX_PATHS paths.  One pass of the rectangle,
+ * rounded up to whole 8x8 pixel blocks, must fit (e.g. 512 x 512 pixels, or the reference's
+ * 128 x 72 tiles many passes at a time); larger rectangles and max_depth above
+ * RT_HIP_NOALLOC_MAX_DEPTH are refused with an error.  Always runs the pipeline of kernels
+ * (RT_HIP_FLAG_FUSED and ray binning do not apply).  All renderers on one GPU share the
+ * array: calls that overlap on one GPU (different handles on different streams) race. */
+#define RT_HIP_NOALLOC_MAX_PATHS (1u << 18)
+#define RT_HIP_NOALLOC_MAX_DEPTH 63u
+int rt_hip_render_noalloc(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
+    uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream);
+
 /* One reference dispatch: one pass of one tile with an explicit random_seed
  * (:650-666), into the renderer's own accumulator.  When the tile is the last
  * of the frame the pass counter advances (:667-669). */

@@ -385,6 +385,7 @@ struct rt_hip_renderer {
     uint32_t wf_extend_grid = 0, wf_extend_waves = 0, wf_shade_grid = 0;  // workgroups, waves
     uint32_t wf_finish_grid = 0;
     uint32_t wf_stat_waves = 0;       // slots of wf.wave_stats
+    wavefront_params noalloc{};       // the same arrays inside this device's scratch array
     uint32_t wf_bin_groups = 0;       // workgroups of the ray binning launches
     bool wf_binned = false;           // the binning buffers exist
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};  // world bounds of the scene
@@ -1071,6 +1072,86 @@ void require_scene(rt_hip_renderer const* r) {
 
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// State of the allocation-free entry point (rt_hip_render_noalloc): the pipeline's path
+// state, lists and control block for at most RT_HIP_NOALLOC_MAX_PATHS paths in flight, in a
+// device array that is part of the loaded code object.  Every GPU the library runs on holds
+// its own copy at its own address for as long as the process lives; rt_hip_create looks that
+// address up once per device (scratch_base) and host code uses only that pointer, never the
+// array's name, which on the host is a stand-in and not a device address.
+constexpr size_t kNoAllocPaths = RT_HIP_NOALLOC_MAX_PATHS;
+constexpr uint32_t kNoAllocTrips = RT_HIP_NOALLOC_MAX_DEPTH + 1u;
+constexpr size_t scratch_align(size_t bytes) { return (bytes + 255u) & ~(size_t) 255u; }
+constexpr size_t kNoAllocChunks = (kNoAllocPaths + 63u) / 64u;
+constexpr size_t kScratchVec4 = scratch_align(kNoAllocPaths * 16u);   // one float4 array
+constexpr size_t kScratchVec2 = scratch_align(kNoAllocPaths * 8u);    // the float2 array
+constexpr size_t kScratchWord = scratch_align(kNoAllocPaths * 4u);    // one u32 array
+constexpr size_t kScratchChunkCounts = scratch_align(kNoAllocChunks * 4u);
+constexpr size_t kScratchTileSums =
+    scratch_align(((kNoAllocChunks + kTileChunks - 1u) / kTileChunks) * 12u);
+constexpr size_t kScratchControl = scratch_align((size_t) (kNoAllocTrips + 1u) * kCtlWords * 4u);
+constexpr size_t kScratchBytes = 8u * kScratchVec4 + kScratchVec2 + 5u * kScratchWord +
+                                 kScratchChunkCounts + kScratchTileSums + kScratchControl;
+static_assert(kScratchBytes <= (size_t) 48u << 20, "keep the resident scratch array modest");
+
+static __device__ __align__(256) unsigned char scratch[kScratchBytes];
+
+constexpr int kMaxDevices = 64;
+static unsigned char* g_scratch_base[kMaxDevices] = {};  // per device; set by rt_hip_create
+
+namespace {
+
+// Looks up this device's copy of `scratch` (the device must be current).
+unsigned char* scratch_base(int device) {
+    if (device < 0 || device >= kMaxDevices) {
+        throw std::runtime_error("device ordinal beyond the per-device table");
+    }
+    if (g_scratch_base[device] == nullptr) {
+        void* ptr = nullptr;
+        HIP_CHECK(hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch)));
+        if (ptr == nullptr) {
+            throw std::runtime_error("hipGetSymbolAddress returned no address for the scratch array");
+        }
+        g_scratch_base[device] = static_cast<unsigned char*>(ptr);
+    }
+    return g_scratch_base[device];
+}
+
+// The pipeline's arrays carved out of the device's scratch array.
+wavefront_params carve_scratch(unsigned char* base, unsigned long long* wave_stats) {
+    wavefront_params w{};
+    size_t at = 0;
+    auto take = [&](size_t bytes) {
+        unsigned char* const here = base + at;
+        at += bytes;
+        return here;
+    };
+    w.ray_o = (float4*) take(kScratchVec4);
+    w.ray_d = (float4*) take(kScratchVec4);
+    w.sh_o = (float4*) take(kScratchVec4);
+    w.sh_d = (float4*) take(kScratchVec4);
+    w.nee = (float4*) take(kScratchVec4);
+    w.thr = (float4*) take(kScratchVec4);
+    w.rad = (float4*) take(kScratchVec4);
+    w.hit0 = (float4*) take(kScratchVec4);
+    w.hit1 = (float2*) take(kScratchVec2);
+    w.occluded = (uint32_t*) take(kScratchWord);
+    w.live = (uint32_t*) take(kScratchWord);
+    w.q_closest = (uint32_t*) take(kScratchWord);
+    w.q_shadow = (uint32_t*) take(kScratchWord);
+    w.raw = (uint32_t*) take(kScratchWord);
+    w.chunk_counts = (uint32_t*) take(kScratchChunkCounts);
+    w.tile_sums = (uint32_t*) take(kScratchTileSums);
+    w.control = (uint32_t*) take(kScratchControl);
+    if (at != kScratchBytes) {
+        throw std::logic_error("scratch layout does not add up");
+    }
+    w.wave_stats = wave_stats;
+    return w;
+}
+
+}  // namespace
+
 namespace {
 
 void render_passes(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
@@ -1106,7 +1187,11 @@ void render_passes(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_p
     p.seeds = r->seeds + (size_t) (first_pass - r->seeds_first_pass) * p.tile_count;
     r->follow(stream);
     if (allocation_free) {
-        throw std::logic_error("no allocation-free path in this build");
+        if (p.max_depth > RT_HIP_NOALLOC_MAX_DEPTH) {
+            throw std::runtime_error("render_noalloc: max_depth " + std::to_string(p.max_depth) +
+                                     " exceeds RT_HIP_NOALLOC_MAX_DEPTH");
+        }
+        launch_wavefront(*r, p, stream, &r->noalloc, kNoAllocPaths);
     } else if (r->cfg.flags & RT_HIP_FLAG_FUSED) {
         launch_path_trace(*r, p, stream);
     } else {
@@ -1178,6 +1263,7 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         HIP_CHECK(hipEventCreate(&r->probe_done));
         HIP_CHECK(hipEventCreateWithFlags(&r->last_done, hipEventDisableTiming));
         init_launch_plan(*r);
+        r->noalloc = carve_scratch(scratch_base(r->device), r->wf.wave_stats);
         *out = r.release();
     });
 }
@@ -1337,6 +1423,14 @@ int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pa
     return guarded([&] {
         render_passes(r, camera, first_pass, pass_count, rect, accum_dev, (hipStream_t) stream,
             false);
+    });
+}
+
+int rt_hip_render_noalloc(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
+    uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream) {
+    return guarded([&] {
+        render_passes(r, camera, first_pass, pass_count, rect, accum_dev, (hipStream_t) stream,
+            true);
     });
 }
 

@@ -24,10 +24,12 @@ FLAG_NO_BIN_RAYS = 16
 BINNING_UNDECIDED, BINNING_OFF, BINNING_ON = 0, 1, 2
 KERNEL_RENDER, KERNEL_EXTEND, KERNEL_SHADE = 0, 1, 2
 MISS = 0xFFFFFFFF
+NOALLOC_MAX_PATHS = 1 << 18
+NOALLOC_MAX_DEPTH = 63
 
 EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
-    "rt_hip_render", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
+    "rt_hip_render", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
@@ -73,6 +75,7 @@ def lib():
         l.rt_hip_clear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
         l.rt_hip_render.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
                                     u32p, C.c_void_p, C.c_void_p]
+        l.rt_hip_render_noalloc.argtypes = l.rt_hip_render.argtypes
         l.rt_hip_render_tile.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p]
         l.rt_hip_render_preview.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32,
@@ -126,6 +129,13 @@ class HipRenderer:
         r = (C.c_uint32 * 4)(*rect) if rect is not None else None
         _check(lib().rt_hip_render(self._h, C.byref(camera), first_pass, pass_count, r,
                                    accum_dev, stream))
+
+    def render_noalloc(self, camera, first_pass, pass_count, rect=None, accum_dev=None,
+                       stream=None):
+        """rt_hip_render without any device allocation: state in the library's fixed array."""
+        r = (C.c_uint32 * 4)(*rect) if rect is not None else None
+        _check(lib().rt_hip_render_noalloc(self._h, C.byref(camera), first_pass, pass_count, r,
+                                           accum_dev, stream))
 
     def render_tile(self, camera, random_seed, tile_x, tile_y, stream=None):
         _check(lib().rt_hip_render_tile(self._h, C.byref(camera), random_seed, tile_x, tile_y,

@@ -1,0 +1,83 @@
+"""rt_hip_render_noalloc: the pipeline with its path state in the library's fixed device array.
+
+It must give the image and the work counters of rt_hip_render bit for bit, call after call: the
+array keeps the previous call's contents, so the second call of each pair below is smaller than
+the first (fewer passes, smaller rectangle) and would pick up stale list entries or counts if
+anything that has to start at zero were not cleared."""
+import numpy as np
+import pytest
+
+from raytracing_amd import hip, host
+
+pytestmark = pytest.mark.gpu
+
+COUNTERS = ["samples", "closest_rays", "shadow_rays", "closest_hits", "shadow_skipped"]
+
+
+def same(a, b):
+    return np.array_equal(a, b, equal_nan=True)
+
+
+def render_pair(r, cam, calls, allocation_free):
+    """Runs `calls` = [(first_pass, pass_count, rect)] in a row; image and counters after each."""
+    out = []
+    for first, count, rect in calls:
+        r.clear()
+        r.stats(reset=True)
+        if allocation_free:
+            r.render_noalloc(cam, first, count, rect=rect)
+        else:
+            r.render(cam, first, count, rect=rect)
+        img, _ = r.read_accum()
+        out.append((img, r.stats()))
+    return out
+
+
+@pytest.mark.parametrize("accel", [hip.ACCEL_REBUILT, hip.ACCEL_REFERENCE])
+@pytest.mark.parametrize("scene_name", ["cornell", "hyperion"])
+def test_noalloc_equals_render_twice_in_a_row(request, scene_name, accel):
+    scene = request.getfixturevalue(scene_name)
+    w, h, md, tile = 640, 360, 7, (64, 36)
+    cam = scene.camera(w, h)
+    # 1st: 512 x 320 pixels = 163 840 paths per pass, 3 passes -> two batches (1 + 1 ... of the
+    # 262 144-path array: one pass per batch); 2nd: a ragged 203 x 117 rectangle, 2 passes, one batch
+    calls = [(0, 3, (64, 20, 576, 340)), (3, 2, (101, 50, 304, 167))]
+    r = hip.HipRenderer(w, h, md, tile, accel=accel)
+    try:
+        r.upload_scene(scene.desc)
+        r.upload_seeds(host.seed_schedule(0, 5, r.tile_count))
+        plain = render_pair(r, cam, calls, allocation_free=False)
+        fixed = render_pair(r, cam, calls, allocation_free=True)
+        again = render_pair(r, cam, calls[::-1], allocation_free=True)[::-1]
+    finally:
+        r.close()
+    for k, (a, b, c) in enumerate(zip(plain, fixed, again)):
+        assert np.isfinite(a[0][..., :3]).any() and a[0][..., :3].max() > 0.0
+        assert same(a[0], b[0]), f"call {k}"
+        assert same(a[0], c[0]), f"call {k}, other order"
+        for name in COUNTERS:
+            assert a[1][name] == b[1][name] == c[1][name], (k, name)
+
+
+def test_noalloc_refuses_what_does_not_fit(cornell):
+    w, h, tile = 1280, 720, (128, 72)
+    r = hip.HipRenderer(w, h, 5, tile)
+    try:
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, 1, r.tile_count))
+        cam = cornell.camera(w, h)
+        with pytest.raises(RuntimeError, match="more than the 262144"):
+            r.render_noalloc(cam, 0, 1)                       # 921 600 paths per pass
+        r.render_noalloc(cam, 0, 1, rect=(0, 0, 512, 512))    # exactly the capacity
+        with pytest.raises(RuntimeError, match="more than the 262144"):
+            r.render_noalloc(cam, 0, 1, rect=(0, 0, 513, 512))
+    finally:
+        r.close()
+    r = hip.HipRenderer(160, 96, 64, (32, 24))
+    try:
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, 1, r.tile_count))
+        with pytest.raises(RuntimeError, match="RT_HIP_NOALLOC_MAX_DEPTH"):
+            r.render_noalloc(cornell.camera(160, 96), 0, 1)
+    finally:
+        r.close()
