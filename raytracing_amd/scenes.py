@@ -31,6 +31,33 @@ def load_snapshot(name):
     return host.HostScene.from_snapshot(path)
 
 
+GENERATED = ("synthetic_4k",)
+
+
+def load(name):
+    """A scene by name: a snapshot of one of the reference's scenes, or a generated one
+    (`synthetic_4k`: 10 000 instances of one 15 872-triangle sphere on a jittered 100 x 100
+    grid, three area lights, constant sky; written in the reference's scene format with a fixed
+    seed and read back through the normal loader)."""
+    if name == "synthetic_4k":
+        import shutil
+        import tempfile
+        directory = tempfile.mkdtemp(prefix="rt_synthetic_4k_")
+        try:
+            return host.HostScene.from_json(write_instanced_scene(directory))
+        finally:
+            shutil.rmtree(directory, ignore_errors=True)
+    return load_snapshot(name)
+
+
+def describe(name):
+    if name in GENERATED:
+        return ("synthetic: generated scene (fixed seed, reference scene format, loaded through "
+                "the host loader), seeds and accumulator resident")
+    return ("synthetic camera samples on a snapshot of the reference scene's loader output "
+            "(tests/golden/scenes), resident in HBM")
+
+
 # ---------------------------------------------------------------------------------------------
 # generated geometry
 

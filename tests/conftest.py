@@ -85,3 +85,11 @@ def instanced(tmp_path_factory):
     path = scenes.write_instanced_scene(str(d), grid=40, sphere_segments=24, sphere_rings=12,
                                         resolution=(320, 180), tile=(64, 36))
     return host.HostScene.from_json(path)
+
+
+@pytest.fixture(scope="session")
+def synthetic_4k():
+    """The generated 4K configuration: 10 000 instances of one 15 872-triangle sphere (159 M
+    instanced triangles), three area lights, constant sky (raytracing_amd/scenes.py)."""
+    from raytracing_amd import scenes
+    return scenes.load("synthetic_4k")

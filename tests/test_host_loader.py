@@ -192,3 +192,24 @@ def test_loader_errors(tmp_path):
     json.dump(doc, open(path, "w"))
     with pytest.raises(RuntimeError, match="no light"):
         host.HostScene.from_json(path)
+
+
+def test_synthetic_4k_generator_is_deterministic(tmp_path):
+    """The 4K configuration is generated, not stored: two runs must write the same bytes, and the
+    loader must turn 10 000 primitives that name one mesh path into 10 000 instances of one mesh
+    (src/asset/scene.cpp:72-90)."""
+    import hashlib
+    from raytracing_amd import host, scenes
+    digests = []
+    for k in range(2):
+        d = tmp_path / f"run{k}"
+        path = scenes.write_instanced_scene(str(d))
+        h = hashlib.sha256()
+        for name in ("instanced.json", "meshes/sphere.obj", "meshes/floor.obj", "meshes/light.obj"):
+            h.update((d / name).read_bytes())
+        digests.append(h.hexdigest())
+    assert digests[0] == digests[1]
+    sc = host.HostScene.from_json(path)
+    assert sc.desc.instance_count == 10_004 and sc.desc.mesh_count == 3
+    assert sc.desc.transform_count == 10_004
+    assert (sc.info.resolution_x, sc.info.resolution_y, sc.info.max_depth) == (3840, 2160, 7)
