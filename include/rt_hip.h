@@ -154,6 +154,51 @@ int rt_hip_render_preview(rt_hip_renderer* r, const rt_camera* preview_camera,
 int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pass,
     uint32_t* instance_ids, uint32_t* triangle_ids, float* hit_t, float* bary);
 
+/* Known-answer probes (no counterpart in the reference): evaluates ONE device function of the
+ * path - the same code the render kernels call - on each of `count` caller-supplied records
+ * and returns the results, so that each function can be checked against the reference shader's
+ * definition on its own.  `in` and `out` are host arrays.  Kinds and their record layout:
+ *
+ *   RAND01          u[0] = seed                      -> f[k] = k-th rand_01, u[k] = state after it (k < 16)
+ *   HASH_COMBINE    u[0] = seed, u[1] = value        -> u[0]
+ *   RAND_UINT       u[0] = seed, u[1] = lo, u[2] = hi -> u[0] = value, u[1] = state after
+ *   HIT_AABB        f[0..5] = x_min x_max y_min y_max z_min z_max, f[6..8] = origin,
+ *                   f[9..11] = direction, f[12] = t_min, f[13] = t_max
+ *                                                    -> u[0] = hit_aabb (ray.glsl:11-31),
+ *                                                       u[1] = the rebuilt structure's widened test (t_min 0)
+ *   HIT_TRIANGLE    f[0..8] = a b c, f[9..11] = origin, f[12..14] = direction, f[15] = t_max
+ *                                                    -> u[0] = hit, f[0..3] = b0 b1 b2 t
+ *   EVAL_DISNEY     material (no textures), u[0] = front_face, f[0..2] = normal,
+ *                   f[3..5] = incoming ray direction, f[6..8] = L  -> f[0..3] = f * |cos|, pdf
+ *   SAMPLE_DISNEY   material, u[0] = front_face, u[1] = seed, f[0..2] = normal,
+ *                   f[3..5] = incoming ray direction -> f[0..2] = L, u[0] = state after
+ *   SAMPLE_TEXTURE  u[0] = texture index of the uploaded scene, f[0] = u, f[1] = v -> f[0..3] = texel
+ *   SKY             f[0..2] = direction              -> f[0..3] = radiance, pdf (uploaded scene's sky)
+ *
+ * SAMPLE_TEXTURE and SKY need an uploaded scene; the others work on any renderer. */
+enum {
+    RT_HIP_PROBE_RAND01 = 0,
+    RT_HIP_PROBE_HASH_COMBINE = 1,
+    RT_HIP_PROBE_RAND_UINT = 2,
+    RT_HIP_PROBE_HIT_AABB = 3,
+    RT_HIP_PROBE_HIT_TRIANGLE = 4,
+    RT_HIP_PROBE_EVAL_DISNEY = 5,
+    RT_HIP_PROBE_SAMPLE_DISNEY = 6,
+    RT_HIP_PROBE_SAMPLE_TEXTURE = 7,
+    RT_HIP_PROBE_SKY = 8
+};
+typedef struct rt_hip_probe_in {
+    uint32_t u[4];
+    float f[16];
+    rt_material material;
+} rt_hip_probe_in;
+typedef struct rt_hip_probe_out {
+    uint32_t u[16];
+    float f[16];
+} rt_hip_probe_out;
+int rt_hip_probe(rt_hip_renderer* r, uint32_t kind, uint32_t count, const rt_hip_probe_in* in,
+    rt_hip_probe_out* out);
+
 /* Synchronises `stream`, then copies the renderer's own accumulator (W*H*4 floats)
  * / preview image ((W/10)*(H/10)*4 floats) to the host.  *passes = number
  * of complete passes accumulated so far (the reference's accumulation_counter). */

@@ -55,6 +55,8 @@ def lib():
         l.oracle_sample_disney.restype = None
         l.oracle_sample_texture.argtypes = [C.POINTER(T.Texture), C.c_float, C.c_float, fp]
         l.oracle_sample_texture.restype = None
+        l.oracle_eval_sky_light.argtypes = [C.POINTER(T.SceneDesc), fp, fp]
+        l.oracle_eval_sky_light.restype = None
         _lib = l
     return _lib
 
@@ -185,4 +187,11 @@ def sample_disney(material, front_face, normal, v_in, seed):
 def sample_texture(texture, u, v):
     out = np.zeros(4, dtype=np.float32)
     lib().oracle_sample_texture(C.byref(texture), u, v, _fp(out))
+    return out
+
+
+def eval_sky_light(desc, direction):
+    direction = _f(direction)
+    out = np.zeros(4, dtype=np.float32)
+    lib().oracle_eval_sky_light(C.byref(desc), _fp(direction), _fp(out))
     return out

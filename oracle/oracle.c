@@ -1442,3 +1442,17 @@ void oracle_sample_texture(const rt_texture* texture, float u, float v, float ou
     out[2] = r.z;
     out[3] = r.w;
 }
+
+void oracle_eval_sky_light(const rt_scene_desc* scene, const float direction[3], float out[4]) {
+    ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.sc = scene;
+    ray_t ray;
+    ray.origin = splat(0.0f);
+    ray.direction = from3(direction);
+    v4 const r = eval_sky_light(&c, ray);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+    out[3] = r.w;
+}

@@ -92,6 +92,8 @@ void oracle_sample_disney(const rt_material* material, int front_face, const flo
 
 /* Bilinear REPEAT fetch used for texture(): out = rgba. */
 void oracle_sample_texture(const rt_texture* texture, float u, float v, float out[4]);
+/* eval_sky_light (megakernel_raytracer.comp:413-438) of the scene's sky: radiance rgb, pdf. */
+void oracle_eval_sky_light(const rt_scene_desc* scene, const float direction[3], float out[4]);
 
 #ifdef __cplusplus
 }

@@ -15,6 +15,7 @@
 #include "accel_build.h"
 #include "rt_hip.h"
 #include "rt_path.h"
+#include "rt_probe.h"
 #include "rt_wavefront.h"
 
 using namespace rtd;
@@ -1541,6 +1542,62 @@ int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pas
         for (void* d : temps) {
             (void) hipFree(d);
         }
+    });
+}
+
+int rt_hip_probe(rt_hip_renderer* r, uint32_t kind, uint32_t count, const rt_hip_probe_in* in,
+    rt_hip_probe_out* out) {
+    return guarded([&] {
+        if (!r || !in || !out) {
+            throw std::runtime_error("probe: null argument");
+        }
+        if (kind > RT_HIP_PROBE_SKY) {
+            throw std::runtime_error("probe: unknown kind");
+        }
+        if (count == 0) {
+            return;
+        }
+        bool const needs_scene = kind == RT_HIP_PROBE_SAMPLE_TEXTURE || kind == RT_HIP_PROBE_SKY;
+        if (needs_scene && !r->scene_ready) {
+            throw std::runtime_error("probe: this kind needs an uploaded scene");
+        }
+        // every index a probe will follow is checked here, on the host
+        for (uint32_t i = 0; i < count; ++i) {
+            if (kind == RT_HIP_PROBE_SAMPLE_TEXTURE && in[i].u[0] >= r->sc.texture_count) {
+                throw std::runtime_error("probe: texture index out of range");
+            }
+            if (kind == RT_HIP_PROBE_EVAL_DISNEY || kind == RT_HIP_PROBE_SAMPLE_DISNEY) {
+                rt_material const& m = in[i].material;
+                if (m.albedo_tex >= 0 || m.emission_tex >= 0 || m.normal_tex >= 0 ||
+                    m.metallic_roughness_tex >= 0) {
+                    throw std::runtime_error("probe: BSDF probes take untextured materials");
+                }
+            }
+            if (kind == RT_HIP_PROBE_RAND_UINT && in[i].u[2] < in[i].u[1]) {
+                throw std::runtime_error("probe: rand_uint range");
+            }
+        }
+        device_scope const on_device(r->device);
+        rt_hip_probe_in* d_in = nullptr;
+        rt_hip_probe_out* d_out = nullptr;
+        try {
+            HIP_CHECK(hipMalloc((void**) &d_in, (size_t) count * sizeof(rt_hip_probe_in)));
+            HIP_CHECK(hipMalloc((void**) &d_out, (size_t) count * sizeof(rt_hip_probe_out)));
+            HIP_CHECK(hipMemcpy(d_in, in, (size_t) count * sizeof(rt_hip_probe_in),
+                hipMemcpyHostToDevice));
+            hipLaunchKernelGGL(probe_kernel, dim3((count + 63u) / 64u), dim3(64), 0, nullptr,
+                r->scene_ready ? r->sc : scene_dev{}, kind, count, d_in, d_out);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipDeviceSynchronize());
+            HIP_CHECK(hipMemcpy(out, d_out, (size_t) count * sizeof(rt_hip_probe_out),
+                hipMemcpyDeviceToHost));
+        } catch (...) {
+            (void) hipFree(d_in);
+            (void) hipFree(d_out);
+            throw;
+        }
+        (void) hipFree(d_in);
+        (void) hipFree(d_out);
     });
 }
 

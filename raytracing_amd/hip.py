@@ -30,7 +30,7 @@ NOALLOC_MAX_DEPTH = 63
 EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
     "rt_hip_render", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
-    "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
+    "rt_hip_probe", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
     "rt_hip_trace_work", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
@@ -48,6 +48,18 @@ class TraceWork(C.Structure):
         "nodes", "tris", "nodes_from_lds", "instance_records", "instance_records_from_lds",
         "finish_nodes", "finish_tris", "node_bytes", "node_bytes_cached", "triangle_bytes",
         "instance_bytes")]
+
+
+PROBE_RAND01, PROBE_HASH_COMBINE, PROBE_RAND_UINT, PROBE_HIT_AABB, PROBE_HIT_TRIANGLE, \
+    PROBE_EVAL_DISNEY, PROBE_SAMPLE_DISNEY, PROBE_SAMPLE_TEXTURE, PROBE_SKY = range(9)
+
+
+class ProbeIn(C.Structure):
+    _fields_ = [("u", C.c_uint32 * 4), ("f", C.c_float * 16), ("material", T.Material)]
+
+
+class ProbeOut(C.Structure):
+    _fields_ = [("u", C.c_uint32 * 16), ("f", C.c_float * 16)]
 
 
 fp = C.POINTER(C.c_float)
@@ -82,6 +94,8 @@ def lib():
                                             C.c_void_p]
         l.rt_hip_primary_ids.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, u32p, u32p,
                                          fp, fp]
+        l.rt_hip_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(ProbeIn),
+                                   C.POINTER(ProbeOut)]
         l.rt_hip_read_accum.argtypes = [C.c_void_p, fp, u32p, C.c_void_p]
         l.rt_hip_read_preview.argtypes = [C.c_void_p, fp, C.c_void_p]
         l.rt_hip_accum_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -154,6 +168,23 @@ class HipRenderer:
                                         inst.ctypes.data_as(u32p), tri.ctypes.data_as(u32p),
                                         t.ctypes.data_as(fp), bary.ctypes.data_as(fp)))
         return inst, tri, t, bary
+
+    def probe(self, kind, records):
+        """Evaluates one device function per record (rt_hip_probe).  records: list of
+        (u, f, material-or-None); returns (u [n, 16] uint32, f [n, 16] float32)."""
+        n = len(records)
+        arr = (ProbeIn * n)()
+        for i, (u, f, material) in enumerate(records):
+            for k, v in enumerate(u):
+                arr[i].u[k] = int(v)
+            for k, v in enumerate(f):
+                arr[i].f[k] = float(v)
+            if material is not None:
+                arr[i].material = material
+        out = (ProbeOut * n)()
+        _check(lib().rt_hip_probe(self._h, kind, n, arr, out))
+        flat = np.frombuffer(out, dtype=np.uint32).reshape(n, 32)
+        return flat[:, :16].copy(), flat[:, 16:].copy().view(np.float32)
 
     def read_accum(self, stream=None):
         out = np.empty((self.height, self.width, 4), dtype=np.float32)
