@@ -62,7 +62,15 @@ enum {
      * cost of tracing that bounce's rays in the first large render call, see
      * rt_hip_ray_binning.  The flags force it on (every bounce) or off. */
     RT_HIP_FLAG_BIN_RAYS = 8u,
-    RT_HIP_FLAG_NO_BIN_RAYS = 16u
+    RT_HIP_FLAG_NO_BIN_RAYS = 16u,
+    /* Opt-in, changes the image's noise (not what it converges to being the point): light
+     * samples on an environment-mapped sky are drawn in proportion to the map's brightness
+     * (a luminance x sin(theta) distribution over its texels, built at upload) instead of the
+     * reference's uniform direction (megakernel_raytracer.comp:447-457), and the sky's pdf
+     * (:431-436) becomes the density of that distribution, for the light sample and for the
+     * MIS weight of BSDF-sampled rays that reach the sky alike.  Without the flag, and for a
+     * sky without a map, sampling is the reference's. */
+    RT_HIP_FLAG_SKY_IMPORTANCE = 32u
 };
 
 enum {
@@ -175,7 +183,11 @@ int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pas
  *   SAMPLE_TEXTURE  u[0] = texture index of the uploaded scene, f[0] = u, f[1] = v -> f[0..3] = texel
  *   SKY             f[0..2] = direction              -> f[0..3] = radiance, pdf (uploaded scene's sky)
  *
- * SAMPLE_TEXTURE and SKY need an uploaded scene; the others work on any renderer. */
+ *   SKY_SAMPLE      u[0] = seed                      -> f[0..2] = direction drawn from the opt-in sky
+ *                                                       distribution, f[3] = its pdf, u[0] = state after
+ *
+ * SAMPLE_TEXTURE, SKY and SKY_SAMPLE need an uploaded scene (SKY_SAMPLE one uploaded with
+ * RT_HIP_FLAG_SKY_IMPORTANCE and an environment map); the others work on any renderer. */
 enum {
     RT_HIP_PROBE_RAND01 = 0,
     RT_HIP_PROBE_HASH_COMBINE = 1,
@@ -185,7 +197,8 @@ enum {
     RT_HIP_PROBE_EVAL_DISNEY = 5,
     RT_HIP_PROBE_SAMPLE_DISNEY = 6,
     RT_HIP_PROBE_SAMPLE_TEXTURE = 7,
-    RT_HIP_PROBE_SKY = 8
+    RT_HIP_PROBE_SKY = 8,
+    RT_HIP_PROBE_SKY_SAMPLE = 9
 };
 typedef struct rt_hip_probe_in {
     uint32_t u[4];
@@ -207,6 +220,17 @@ int rt_hip_read_preview(rt_hip_renderer* r, float* rgba, void* stream);
 
 /* Device address of the renderer's own accumulator (for a collective). */
 int rt_hip_accum_ptr(rt_hip_renderer* r, void** accum_dev);
+
+/* Multi-GPU (no counterpart in the reference, which drives one device): the scene is uploaded
+ * to one renderer per GPU (rt_hip_config.device), each traces its own range of passes of the
+ * whole frame into its own accumulator, and this call sums the accumulators onto
+ * renderers[0]'s: renderers that share a GPU are added by a kernel, the per-GPU sums are
+ * combined by ONE RCCL sum-reduce (W*H*4 floats; xGMI between the GPUs of a node).  The other
+ * renderers are left cleared with a pass count of zero, so accumulation can go on;
+ * renderers[0]'s pass count becomes the total and its alpha channel stays 1.  Waits for all
+ * outstanding work of every listed renderer and returns when the sum is complete.  librccl is
+ * loaded on first use and only when two GPUs are involved. */
+int rt_hip_reduce(rt_hip_renderer* const* renderers, uint32_t count);
 
 /* Complete passes accumulated so far in the renderer's own accumulator (the
  * reference's accumulation_counter, megakernel_raytracer.cpp:109, :667-669).

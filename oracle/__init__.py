@@ -25,7 +25,8 @@ class Params(C.Structure):
                 ("first_pass", C.c_uint32), ("pass_count", C.c_uint32), ("preview", C.c_uint32),
                 ("seeds", u32p),
                 ("rect_x0", C.c_uint32), ("rect_y0", C.c_uint32), ("rect_x1", C.c_uint32),
-                ("rect_y1", C.c_uint32), ("threads", C.c_uint32)]
+                ("rect_y1", C.c_uint32), ("threads", C.c_uint32),
+                ("sky_importance", C.c_uint32)]
 
 
 def lib():
@@ -57,6 +58,16 @@ def lib():
         l.oracle_sample_texture.restype = None
         l.oracle_eval_sky_light.argtypes = [C.POINTER(T.SceneDesc), fp, fp]
         l.oracle_eval_sky_light.restype = None
+        l.oracle_eval_sky_light_importance.argtypes = [C.POINTER(T.SceneDesc), fp, fp]
+        l.oracle_eval_sky_light_importance.restype = None
+        l.oracle_eval_sky_light_many.argtypes = [C.POINTER(T.SceneDesc), C.c_int, C.c_uint32, fp,
+                                                 fp]
+        l.oracle_eval_sky_light_many.restype = None
+        l.oracle_sample_sky_importance.argtypes = [C.POINTER(T.SceneDesc), u32p, fp]
+        l.oracle_sample_sky_importance.restype = None
+        l.oracle_sample_sky_importance_many.argtypes = [C.POINTER(T.SceneDesc), C.c_uint32,
+                                                        C.c_uint32, fp, fp]
+        l.oracle_sample_sky_importance_many.restype = None
         _lib = l
     return _lib
 
@@ -70,7 +81,7 @@ def _fp(a):
 
 
 def _params(width, height, max_depth, tile, seeds, first_pass=0, preview=False, rect=None,
-            threads=0):
+            threads=0, sky_importance=False):
     seeds = np.ascontiguousarray(seeds, dtype=np.uint32)
     tiles = (width // tile[0]) * (height // tile[1])
     assert seeds.ndim == 2 and seeds.shape[1] == tiles, (seeds.shape, tiles)
@@ -83,16 +94,18 @@ def _params(width, height, max_depth, tile, seeds, first_pass=0, preview=False, 
     if rect is not None:
         p.rect_x0, p.rect_y0, p.rect_x1, p.rect_y1 = rect
     p.threads = threads
+    p.sky_importance = 1 if sky_importance else 0
     return p, seeds
 
 
 def render(desc, camera, width, height, max_depth, tile, seeds, accum=None, first_pass=0,
-           preview=False, rect=None, threads=0):
+           preview=False, rect=None, threads=0, sky_importance=False):
     """Adds seeds.shape[0] passes to `accum` (H, W, 4 float32; created when None).
 
     Returns (accum, stats_dict).
     """
-    p, seeds = _params(width, height, max_depth, tile, seeds, first_pass, preview, rect, threads)
+    p, seeds = _params(width, height, max_depth, tile, seeds, first_pass, preview, rect, threads,
+                       sky_importance)
     if accum is None:
         accum = np.zeros((height, width, 4), dtype=np.float32)
     assert accum.dtype == np.float32 and accum.shape == (height, width, 4)
@@ -190,8 +203,32 @@ def sample_texture(texture, u, v):
     return out
 
 
-def eval_sky_light(desc, direction):
+def eval_sky_light(desc, direction, importance=False):
     direction = _f(direction)
     out = np.zeros(4, dtype=np.float32)
-    lib().oracle_eval_sky_light(C.byref(desc), _fp(direction), _fp(out))
+    call = lib().oracle_eval_sky_light_importance if importance else lib().oracle_eval_sky_light
+    call(C.byref(desc), _fp(direction), _fp(out))
+    return out
+
+
+def sample_sky_importance(desc, seed):
+    out = np.zeros(3, dtype=np.float32)
+    s = C.c_uint32(seed)
+    lib().oracle_sample_sky_importance(C.byref(desc), C.byref(s), _fp(out))
+    return out, s.value
+
+
+def sample_sky_importance_many(desc, seed, n):
+    directions = np.zeros((n, 3), dtype=np.float32)
+    pdfs = np.zeros(n, dtype=np.float32)
+    lib().oracle_sample_sky_importance_many(C.byref(desc), seed, n, _fp(directions), _fp(pdfs))
+    return directions, pdfs
+
+
+def eval_sky_light_many(desc, directions, importance=False):
+    """eval_sky_light for an [n, 3] array of directions: [n, 4] (radiance rgb, pdf)."""
+    directions = _f(directions).reshape(-1, 3)
+    out = np.zeros((len(directions), 4), dtype=np.float32)
+    lib().oracle_eval_sky_light_many(C.byref(desc), 1 if importance else 0, len(directions),
+                                     _fp(directions), _fp(out))
     return out

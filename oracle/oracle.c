@@ -182,6 +182,16 @@ typedef struct {
     uint64_t closest_rays, shadow_rays, closest_hits, nodes, tris, max_stack;
 } counters_t;
 
+/* Opt-in extension (not in the reference, whose sky sampling is uniform,
+ * megakernel_raytracer.comp:447-457): a piecewise-constant distribution over the environment
+ * map's texels, luminance(intensity * tone_mapping(texel)) * sin(theta of the row). */
+struct sky_tables {
+    uint32_t w, h;
+    float* density;     /* [h][w]   pdf over the unit (u, v) square */
+    float* conditional; /* [h][w+1] normalised CDF along each row */
+    float* marginal;    /* [h+1]    CDF over rows */
+};
+
 typedef struct {
     const rt_scene_desc* sc;
     uint32_t max_depth;
@@ -189,6 +199,7 @@ typedef struct {
     counters_t* cnt;
     uint32_t* stack;     /* STACK_CAPACITY words */
     uint32_t* candidates;/* CANDIDATE_CAPACITY words */
+    const struct sky_tables* sky; /* opt-in importance sampling of the environment map, or NULL */
 } ctx_t;
 
 /* shaders/raytracer/ray.glsl:11-31 */
@@ -1028,11 +1039,62 @@ static v4 eval_sky_light(const ctx_t* c, ray_t ray) {
         float const total_luminance = sky->direction[0];
         float const tex_w = sky->direction[1];
         float const tex_h = sky->direction[2];
-        float const padded_sin_theta = pad_above_zero(sinf(theta));
-        r.w = ((luminance(intensity) / total_luminance) * tex_w * tex_h) /
-              ((float) (2.0 * PI_D * PI_D) * padded_sin_theta);
+        if (c->sky != NULL) {
+            uint32_t x = (uint32_t) (u * (float) c->sky->w);
+            uint32_t y = (uint32_t) (v * (float) c->sky->h);
+            if (x > c->sky->w - 1u) {
+                x = c->sky->w - 1u;
+            }
+            if (y > c->sky->h - 1u) {
+                y = c->sky->h - 1u;
+            }
+            float const sin_theta = sinf(theta);
+            r.w = sin_theta > 0.0f ? c->sky->density[(size_t) y * c->sky->w + x] /
+                                         ((float) (2.0 * PI_D * PI_D) * sin_theta)
+                                   : 0.0f;
+        } else {
+            float const padded_sin_theta = pad_above_zero(sinf(theta));
+            r.w = ((luminance(intensity) / total_luminance) * tex_w * tex_h) /
+                  ((float) (2.0 * PI_D * PI_D) * padded_sin_theta);
+        }
     }
     return r;
+}
+
+/* Inverts one CDF of n + 1 entries (cdf[0] = 0, cdf[n] = 1): the largest i with cdf[i] <= r,
+ * the remainder of r placing the sample inside cell i. */
+static float sample_cdf(const float* cdf, uint32_t n, float r) {
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        uint32_t const mid = (lo + hi) >> 1;
+        if (cdf[mid] <= r) {
+            lo = mid;
+        } else {
+            hi = mid;
+        }
+    }
+    float const width = cdf[lo + 1u] - cdf[lo];
+    float within = r - cdf[lo];
+    if (width > 0.0f) {
+        within = within / width;
+    }
+    return ((float) lo + fminf(within, 1.0f)) / (float) n;
+}
+
+static v3 sample_sky_importance(const ctx_t* c) {
+    float const r0 = rand_01(c->seed);
+    float const r1 = rand_01(c->seed);
+    const struct sky_tables* t = c->sky;
+    float const v = sample_cdf(t->marginal, t->h, r0);
+    uint32_t row = (uint32_t) (v * (float) t->h);
+    if (row > t->h - 1u) {
+        row = t->h - 1u;
+    }
+    float const u = sample_cdf(t->conditional + (size_t) row * (t->w + 1u), t->w, r1);
+    float const theta = v * PI;
+    float const phi = u * TWO_PI - PI;
+    float const sin_theta = sinf(theta);
+    return V3(sin_theta * cosf(phi), cosf(theta), sin_theta * sinf(phi));
 }
 
 /* megakernel_raytracer.comp:440-507 */
@@ -1047,7 +1109,9 @@ static int sample_light(ctx_t* c, ray_t ray, v3 position, light_sample_t* ls) {
     float const infinity_light_t_max = (float) ((1.0 / 0.00000000000001) - 0.0001);
     ls->type = light->type;
     if (light->type == RT_LIGHT_SKY) {
-        v3 const direction = uniform_sample_hemisphere(c->seed, ray.direction);
+        int const importance = c->sky != NULL && light->emission_tex >= 0;
+        v3 const direction = importance ? sample_sky_importance(c)
+                                        : uniform_sample_hemisphere(c->seed, ray.direction);
         ray_t shadow_ray;
         shadow_ray.origin = position;
         shadow_ray.direction = direction;
@@ -1055,6 +1119,9 @@ static int sample_light(ctx_t* c, ray_t ray, v3 position, light_sample_t* ls) {
             return 0;
         }
         v4 const ip = eval_sky_light(c, shadow_ray);
+        if (importance && !(ip.w > 0.0f)) {
+            return 0; /* a pole of the map: zero density */
+        }
         ls->intensity = V3(ip.x, ip.y, ip.z);
         ls->pdf = light_pdf * ip.w;
         ls->wi = direction;
@@ -1209,6 +1276,61 @@ static void rect_of(const oracle_params* p, uint32_t* x0, uint32_t* y0, uint32_t
     }
 }
 
+/* The tables of the opt-in sky distribution; sums in double, tables in float. */
+static struct sky_tables* build_sky_tables(const rt_scene_desc* sc) {
+    if (sc->sky_light < 0 || sc->lights[sc->sky_light].emission_tex < 0) {
+        return NULL;
+    }
+    const rt_light* sky = &sc->lights[sc->sky_light];
+    const rt_texture* map = &sc->textures[sky->emission_tex];
+    uint32_t const w = map->width, h = map->height;
+    struct sky_tables* t = (struct sky_tables*) malloc(sizeof(*t));
+    t->w = w;
+    t->h = h;
+    t->density = (float*) malloc(sizeof(float) * (size_t) w * h);
+    t->conditional = (float*) malloc(sizeof(float) * (size_t) h * (w + 1u));
+    t->marginal = (float*) malloc(sizeof(float) * ((size_t) h + 1u));
+    double total = 0.0;
+    for (uint32_t y = 0; y < h; ++y) {
+        float const sin_theta = (sinf)(PI * ((float) y + 0.5f) / (float) h);
+        float* const row = t->conditional + (size_t) y * (w + 1u);
+        double running = 0.0;
+        for (uint32_t x = 0; x < w; ++x) {
+            v4 const texel = load_texel(map, x, y);
+            v3 const mapped = tone_mapping(V3(texel.x, texel.y, texel.z));
+            v3 const rgb = V3(sky->intensity[0] * mapped.x, sky->intensity[1] * mapped.y,
+                sky->intensity[2] * mapped.z);
+            float const f = fmaxf(luminance(rgb), 0.0f) * sin_theta;
+            t->density[(size_t) y * w + x] = f;
+            row[x] = (float) running;
+            running += (double) f / (double) w;
+        }
+        for (uint32_t x = 0; x <= w; ++x) {
+            row[x] = running > 0.0 ? (float) ((double) row[x] / running) : (float) x / (float) w;
+        }
+        row[w] = 1.0f;
+        t->marginal[y] = (float) total;
+        total += running / (double) h;
+    }
+    for (uint32_t y = 0; y < h; ++y) {
+        t->marginal[y] = (float) ((double) t->marginal[y] / total);
+    }
+    t->marginal[h] = 1.0f;
+    for (size_t i = 0; i < (size_t) w * h; ++i) {
+        t->density[i] = (float) ((double) t->density[i] / total);
+    }
+    return t;
+}
+
+static void free_sky_tables(struct sky_tables* t) {
+    if (t) {
+        free(t->density);
+        free(t->conditional);
+        free(t->marginal);
+        free(t);
+    }
+}
+
 int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
     const oracle_params* p, float* accum, rt_stats* stats) {
     if (check_params(scene, p) || !accum) {
@@ -1219,6 +1341,7 @@ int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
     uint32_t const tiles_x = p->width / p->tile_width;
     uint32_t const tiles = tiles_x * (p->height / p->tile_height);
     uint64_t closest = 0, shadow = 0, hits = 0, nodes = 0, tris = 0, max_stack = 0;
+    struct sky_tables* const sky = p->sky_importance ? build_sky_tables(scene) : NULL;
 #ifdef _OPENMP
     if (p->threads > 0) {
         omp_set_num_threads((int) p->threads);
@@ -1233,6 +1356,7 @@ int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
         uint32_t seed = 0;
         ctx_t c;
         c.sc = scene;
+        c.sky = sky;
         c.max_depth = p->max_depth;
         c.seed = &seed;
         c.cnt = &cnt;
@@ -1271,6 +1395,7 @@ int oracle_render(const rt_scene_desc* scene, const rt_camera* camera,
             max_stack = cnt.max_stack;
         }
     }
+    free_sky_tables(sky);
     if (stats) {
         stats->samples += (uint64_t) (x1 - x0) * (y1 - y0) * p->pass_count;
         stats->closest_rays += closest;
@@ -1306,6 +1431,7 @@ int oracle_primary_ids(const rt_scene_desc* scene, const rt_camera* camera,
         uint32_t seed = 0;
         ctx_t c;
         c.sc = scene;
+        c.sky = NULL;
         c.max_depth = p->max_depth;
         c.seed = &seed;
         c.cnt = &cnt;
@@ -1455,4 +1581,81 @@ void oracle_eval_sky_light(const rt_scene_desc* scene, const float direction[3],
     out[1] = r.y;
     out[2] = r.z;
     out[3] = r.w;
+}
+
+void oracle_eval_sky_light_importance(const rt_scene_desc* scene, const float direction[3],
+    float out[4]) {
+    ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.sc = scene;
+    struct sky_tables* const sky = build_sky_tables(scene);
+    c.sky = sky;
+    ray_t ray;
+    ray.origin = splat(0.0f);
+    ray.direction = from3(direction);
+    v4 const r = eval_sky_light(&c, ray);
+    out[0] = r.x;
+    out[1] = r.y;
+    out[2] = r.z;
+    out[3] = r.w;
+    free_sky_tables(sky);
+}
+
+/* One draw from the opt-in sky distribution: the direction and the random state after it. */
+void oracle_sample_sky_importance(const rt_scene_desc* scene, uint32_t* seed, float out[3]) {
+    ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.sc = scene;
+    c.seed = seed;
+    struct sky_tables* const sky = build_sky_tables(scene);
+    c.sky = sky;
+    v3 const d = sample_sky_importance(&c);
+    out[0] = d.x;
+    out[1] = d.y;
+    out[2] = d.z;
+    free_sky_tables(sky);
+}
+
+/* Many draws (the tables are built once): directions[3 * n], pdfs[n]. */
+void oracle_sample_sky_importance_many(const rt_scene_desc* scene, uint32_t seed, uint32_t n,
+    float* directions, float* pdfs) {
+    ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.sc = scene;
+    c.seed = &seed;
+    struct sky_tables* const sky = build_sky_tables(scene);
+    c.sky = sky;
+    for (uint32_t i = 0; i < n; ++i) {
+        v3 const d = sample_sky_importance(&c);
+        directions[3 * i + 0] = d.x;
+        directions[3 * i + 1] = d.y;
+        directions[3 * i + 2] = d.z;
+        ray_t ray;
+        ray.origin = splat(0.0f);
+        ray.direction = d;
+        pdfs[i] = eval_sky_light(&c, ray).w;
+    }
+    free_sky_tables(sky);
+}
+
+/* eval_sky_light for n directions (directions[3 * n] -> out[4 * n]); importance != 0 builds
+ * the opt-in tables once. */
+void oracle_eval_sky_light_many(const rt_scene_desc* scene, int importance, uint32_t n,
+    const float* directions, float* out) {
+    ctx_t c;
+    memset(&c, 0, sizeof(c));
+    c.sc = scene;
+    struct sky_tables* const sky = importance ? build_sky_tables(scene) : NULL;
+    c.sky = sky;
+    for (uint32_t i = 0; i < n; ++i) {
+        ray_t ray;
+        ray.origin = splat(0.0f);
+        ray.direction = from3(directions + 3 * i);
+        v4 const r = eval_sky_light(&c, ray);
+        out[4 * i + 0] = r.x;
+        out[4 * i + 1] = r.y;
+        out[4 * i + 2] = r.z;
+        out[4 * i + 3] = r.w;
+    }
+    free_sky_tables(sky);
 }

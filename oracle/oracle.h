@@ -41,6 +41,10 @@ typedef struct oracle_params {
     uint32_t rect_x0, rect_y0, rect_x1, rect_y1; /* pixel rectangle [x0,x1) x [y0,y1);
                                                      all zero = whole frame */
     uint32_t threads;              /* OpenMP threads; 0 = runtime default */
+    uint32_t sky_importance;       /* opt-in extension, not in the reference: light samples on an
+                                      environment-mapped sky are drawn in proportion to the map
+                                      (luminance x sin theta per texel) and the sky pdf is that
+                                      density; 0 = the shader's uniform sampling */
 } oracle_params;
 
 /* megakernel_raytracer.comp:85-114 for every pixel of the rectangle and every
@@ -94,6 +98,14 @@ void oracle_sample_disney(const rt_material* material, int front_face, const flo
 void oracle_sample_texture(const rt_texture* texture, float u, float v, float out[4]);
 /* eval_sky_light (megakernel_raytracer.comp:413-438) of the scene's sky: radiance rgb, pdf. */
 void oracle_eval_sky_light(const rt_scene_desc* scene, const float direction[3], float out[4]);
+/* The same with the opt-in sky distribution (oracle_params.sky_importance): its pdf. */
+void oracle_eval_sky_light_importance(const rt_scene_desc* scene, const float direction[3],
+    float out[4]);
+void oracle_eval_sky_light_many(const rt_scene_desc* scene, int importance, uint32_t n,
+    const float* directions, float* out);
+void oracle_sample_sky_importance(const rt_scene_desc* scene, uint32_t* seed, float out[3]);
+void oracle_sample_sky_importance_many(const rt_scene_desc* scene, uint32_t seed, uint32_t n,
+    float* directions, float* pdfs);
 
 #ifdef __cplusplus
 }

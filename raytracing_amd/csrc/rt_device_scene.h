@@ -80,6 +80,13 @@ struct scene_dev {
     uint32_t stack_entries;
     uint32_t cached_nodes;
     uint32_t cached_instances;
+    // Opt-in importance sampling of the environment map (null / 0 = the reference's sampling):
+    // density[y * w + x] = probability density of texel (x, y) over the unit (u, v) square,
+    // conditional[y * (w + 1) + x] = normalised CDF along row y, marginal[y] = CDF over rows.
+    const float* sky_density;
+    const float* sky_conditional;
+    const float* sky_marginal;
+    uint32_t sky_w, sky_h;
     // sizes of the small tables the shading kernel may stage in LDS
     uint32_t instance_count, transform_count, material_count, mesh_count, texture_count;
 };

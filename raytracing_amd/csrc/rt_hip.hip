@@ -4,10 +4,14 @@
 // the kernels is written explicitly (rt_traverse_fast.h), everything else is
 // plain IEEE binary32 so results can be compared with the CPU oracle.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>  // types and prototypes only: the library is loaded on first use
 
 #include <cstdio>
 #include <cstring>
+#include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -285,6 +289,25 @@ __global__ void clear_rgba_kernel(float4* img, size_t count) {
     size_t const i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
         img[i] = make_float4(0.0f, 0.0f, 0.0f, 1.0f);
+    }
+}
+
+// dst += src on the colour channels; alpha stays 1 (both hold vec4(colour, 1) sums).
+__global__ void add_rgb_kernel(float4* dst, const float4* src, size_t count) {
+    size_t const i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        float4 a = dst[i];
+        float4 const b = src[i];
+        a.x += b.x, a.y += b.y, a.z += b.z;
+        a.w = 1.0f;
+        dst[i] = a;
+    }
+}
+
+__global__ void set_alpha_kernel(float4* img, size_t count) {
+    size_t const i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        img[i].w = 1.0f;
     }
 }
 
@@ -574,6 +597,73 @@ void validate_scene(rt_scene_desc const& s) {
                  s.textures[i].format <= RT_TEX_F32X4,
             "texture");
     }
+}
+
+// Tables for the opt-in importance sampling of the environment map (rt_shading.h:
+// sample_sky_importance): a piecewise-constant distribution over the map's texels, weighted by
+// the luminance of what eval_sky_light returns for the texel (intensity x Reinhard-mapped
+// texel, megakernel_raytracer.comp:426-430) times sin(theta) of the texel's row (equal areas
+// of the (u, v) square are not equal solid angles).  Sums run in double, tables are float.
+struct sky_tables {
+    uint32_t width = 0, height = 0;
+    std::vector<float> density;      // [h][w]: pdf over the unit (u, v) square
+    std::vector<float> conditional;  // [h][w + 1]: normalised CDF along each row
+    std::vector<float> marginal;     // [h + 1]: CDF over rows
+};
+
+sky_tables build_sky_tables(rt_light const& sky, rt_texture const& map) {
+    sky_tables t;
+    uint32_t const w = map.width, h = map.height;
+    t.width = w;
+    t.height = h;
+    t.density.assign((size_t) w * h, 0.0f);
+    t.conditional.assign((size_t) h * (w + 1u), 0.0f);
+    t.marginal.assign((size_t) h + 1u, 0.0f);
+    std::vector<double> row_sum(h, 0.0);
+    auto channel = [&](size_t texel, int c) -> float {
+        if (map.format == RT_TEX_F32X4) {
+            return static_cast<const float*>(map.data)[texel * 4 + c];
+        }
+        return (float) static_cast<const uint8_t*>(map.data)[texel * 4 + c] / 255.0f;
+    };
+    double total = 0.0;
+    for (uint32_t y = 0; y < h; ++y) {
+        float const sin_theta = sinf(kPi * ((float) y + 0.5f) / (float) h);
+        double running = 0.0;
+        for (uint32_t x = 0; x < w; ++x) {
+            size_t const i = (size_t) y * w + x;
+            float rgb[3];
+            for (int c = 0; c < 3; ++c) {
+                float const v = channel(i, c);
+                rgb[c] = sky.intensity[c] * (v / (v + 1.0f));
+            }
+            float const lum = (0.212671f * rgb[0] + 0.715160f * rgb[1]) + 0.072169f * rgb[2];
+            float const f = fmaxf(lum, 0.0f) * sin_theta;
+            t.density[i] = f;
+            t.conditional[(size_t) y * (w + 1u) + x] = (float) running;
+            running += (double) f / (double) w;
+        }
+        row_sum[y] = running;
+        float* const row = &t.conditional[(size_t) y * (w + 1u)];
+        for (uint32_t x = 0; x <= w; ++x) {
+            row[x] = running > 0.0 ? (float) ((double) row[x] / running) : (float) x / (float) w;
+        }
+        row[w] = 1.0f;
+        t.marginal[y] = (float) total;
+        total += running / (double) h;
+    }
+    if (!(total > 0.0)) {
+        throw std::runtime_error("upload_scene: the environment map is black; it cannot be "
+                                 "importance sampled");
+    }
+    for (uint32_t y = 0; y < h; ++y) {
+        t.marginal[y] = (float) ((double) t.marginal[y] / total);
+    }
+    t.marginal[h] = 1.0f;
+    for (float& f : t.density) {
+        f = (float) ((double) f / total);
+    }
+    return t;
 }
 
 uint32_t ref_depth(rt_bvh_node const* nodes, uint32_t root) {
@@ -1206,6 +1296,174 @@ void render_passes(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_p
 
 }  // namespace
 
+
+// ---------------------------------------------------------------------------
+// Multi-GPU: one sum-reduce of the accumulators over RCCL (xGMI between the GPUs of a node).
+namespace {
+
+struct rccl_api {
+    decltype(&ncclCommInitAll) comm_init_all = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclReduce) reduce = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+// Loaded on the first reduce that needs it, so a single-GPU user never maps RCCL.  A process
+// that already holds an RCCL (PyTorch ships one) shares it.
+rccl_api const& rccl() {
+    static rccl_api api;
+    static std::once_flag once;
+    static std::string failure;
+    std::call_once(once, [] {
+        void* lib = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);
+        for (char const* name : {"librccl.so.1", "librccl.so"}) {
+            if (lib == nullptr) {
+                lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+            }
+        }
+        if (lib == nullptr) {
+            failure = std::string{"cannot load librccl: "} + dlerror();
+            return;
+        }
+        auto find = [&](auto& slot, char const* symbol) {
+            slot = reinterpret_cast<std::remove_reference_t<decltype(slot)>>(dlsym(lib, symbol));
+            if (slot == nullptr && failure.empty()) {
+                failure = std::string{"librccl lacks "} + symbol;
+            }
+        };
+        find(api.comm_init_all, "ncclCommInitAll");
+        find(api.comm_destroy, "ncclCommDestroy");
+        find(api.reduce, "ncclReduce");
+        find(api.group_start, "ncclGroupStart");
+        find(api.group_end, "ncclGroupEnd");
+        find(api.error_string, "ncclGetErrorString");
+    });
+    if (!failure.empty()) {
+        throw std::runtime_error(failure);
+    }
+    return api;
+}
+
+void rccl_check(ncclResult_t code, char const* what) {
+    if (code != ncclSuccess) {
+        throw std::runtime_error(std::string{what} + ": " + rccl().error_string(code));
+    }
+}
+
+// One communicator set per distinct device list, kept for the life of the process
+// (creating one costs tens of milliseconds; a render reduces once).
+std::vector<ncclComm_t> const& communicators(std::vector<int> const& devices) {
+    static std::map<std::vector<int>, std::vector<ncclComm_t>> cache;
+    static std::mutex guard;
+    std::lock_guard<std::mutex> const lock(guard);
+    auto it = cache.find(devices);
+    if (it == cache.end()) {
+        std::vector<ncclComm_t> comms(devices.size());
+        rccl_check(rccl().comm_init_all(comms.data(), (int) devices.size(), devices.data()),
+            "ncclCommInitAll");
+        it = cache.emplace(devices, std::move(comms)).first;
+    }
+    return it->second;
+}
+
+void reduce_renderers(rt_hip_renderer* const* renderers, uint32_t count) {
+    if (!renderers || count == 0) {
+        throw std::runtime_error("reduce: no renderers");
+    }
+    rt_hip_renderer& root = *renderers[0];
+    size_t const pixels = (size_t) root.cfg.width * root.cfg.height;
+    for (uint32_t i = 0; i < count; ++i) {
+        rt_hip_renderer const* r = renderers[i];
+        if (!r) {
+            throw std::runtime_error("reduce: null renderer");
+        }
+        if (r->cfg.width != root.cfg.width || r->cfg.height != root.cfg.height) {
+            throw std::runtime_error("reduce: the renderers' frames differ in size");
+        }
+        for (uint32_t k = 0; k < i; ++k) {
+            if (renderers[k] == r) {
+                throw std::runtime_error("reduce: the same renderer is listed twice");
+            }
+        }
+    }
+    dim3 const grid((uint32_t) ((pixels + 255) / 256)), block(256);
+    // 1. wait for every renderer's work; renderers that share a GPU with an earlier one are
+    //    added to it by a kernel (no transport needed) and cleared
+    std::vector<rt_hip_renderer*> leaders;  // first renderer listed on each device
+    for (uint32_t i = 0; i < count; ++i) {
+        rt_hip_renderer* r = renderers[i];
+        device_scope const on_device(r->device);
+        HIP_CHECK(hipDeviceSynchronize());
+        rt_hip_renderer* leader = nullptr;
+        for (rt_hip_renderer* l : leaders) {
+            if (l->device == r->device) {
+                leader = l;
+            }
+        }
+        if (leader == nullptr) {
+            leaders.push_back(r);
+            continue;
+        }
+        hipLaunchKernelGGL(add_rgb_kernel, grid, block, 0, nullptr,
+            reinterpret_cast<float4*>(leader->accum), reinterpret_cast<const float4*>(r->accum),
+            pixels);
+        HIP_CHECK(hipGetLastError());
+        hipLaunchKernelGGL(clear_rgba_kernel, grid, block, 0, nullptr,
+            reinterpret_cast<float4*>(r->accum), pixels);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    // 2. one RCCL sum-reduce of the per-GPU accumulators onto the root's GPU
+    static bool const always_rccl = [] {
+        char const* v = getenv("RT_HIP_REDUCE_ALWAYS_RCCL");  // lets a one-GPU test drive RCCL
+        return v && atoi(v) != 0;
+    }();
+    if (leaders.size() > 1 || always_rccl) {
+        std::vector<int> devices;
+        for (rt_hip_renderer* l : leaders) {
+            devices.push_back(l->device);
+        }
+        std::vector<ncclComm_t> const& comms = communicators(devices);
+        rccl_check(rccl().group_start(), "ncclGroupStart");
+        for (size_t k = 0; k < leaders.size(); ++k) {
+            device_scope const on_device(leaders[k]->device);
+            rccl_check(rccl().reduce(leaders[k]->accum, k == 0 ? root.accum : nullptr, pixels * 4,
+                           ncclFloat, ncclSum, 0, comms[k], nullptr),
+                "ncclReduce");
+        }
+        rccl_check(rccl().group_end(), "ncclGroupEnd");
+        for (size_t k = 0; k < leaders.size(); ++k) {
+            device_scope const on_device(leaders[k]->device);
+            HIP_CHECK(hipDeviceSynchronize());
+            if (k > 0) {
+                hipLaunchKernelGGL(clear_rgba_kernel, grid, block, 0, nullptr,
+                    reinterpret_cast<float4*>(leaders[k]->accum), pixels);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipDeviceSynchronize());
+            }
+        }
+    }
+    // 3. alpha back to 1 (the sum of N images holds N), pass counters
+    {
+        device_scope const on_device(root.device);
+        hipLaunchKernelGGL(set_alpha_kernel, grid, block, 0, nullptr,
+            reinterpret_cast<float4*>(root.accum), pixels);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipDeviceSynchronize());
+    }
+    for (uint32_t i = 1; i < count; ++i) {
+        root.passes_done += renderers[i]->passes_done;
+        renderers[i]->passes_done = 0;
+        renderers[i]->tile_cursor = 0;
+        renderers[i]->last_recorded = false;
+    }
+    root.last_recorded = false;
+}
+
+}  // namespace
+
 // ---------------------------------------------------------------------------
 // C ABI
 
@@ -1307,6 +1565,16 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         d.material_count = s.material_count;
         d.mesh_count = s.mesh_count;
         d.texture_count = s.texture_count;
+        if ((r->cfg.flags & RT_HIP_FLAG_SKY_IMPORTANCE) && s.sky_light >= 0 &&
+            s.lights[s.sky_light].emission_tex >= 0) {
+            sky_tables const t = build_sky_tables(s.lights[s.sky_light],
+                s.textures[s.lights[s.sky_light].emission_tex]);
+            d.sky_density = r->upload(t.density.data(), t.density.size());
+            d.sky_conditional = r->upload(t.conditional.data(), t.conditional.size());
+            d.sky_marginal = r->upload(t.marginal.data(), t.marginal.size());
+            d.sky_w = t.width;
+            d.sky_h = t.height;
+        }
         if (r->cfg.accel == RT_HIP_ACCEL_REFERENCE) {
             uint32_t blas_depth = 0;
             for (uint32_t m = 0; m < s.mesh_count; ++m) {
@@ -1551,15 +1819,20 @@ int rt_hip_probe(rt_hip_renderer* r, uint32_t kind, uint32_t count, const rt_hip
         if (!r || !in || !out) {
             throw std::runtime_error("probe: null argument");
         }
-        if (kind > RT_HIP_PROBE_SKY) {
+        if (kind > RT_HIP_PROBE_SKY_SAMPLE) {
             throw std::runtime_error("probe: unknown kind");
         }
         if (count == 0) {
             return;
         }
-        bool const needs_scene = kind == RT_HIP_PROBE_SAMPLE_TEXTURE || kind == RT_HIP_PROBE_SKY;
+        bool const needs_scene = kind == RT_HIP_PROBE_SAMPLE_TEXTURE ||
+                                 kind == RT_HIP_PROBE_SKY || kind == RT_HIP_PROBE_SKY_SAMPLE;
         if (needs_scene && !r->scene_ready) {
             throw std::runtime_error("probe: this kind needs an uploaded scene");
+        }
+        if (kind == RT_HIP_PROBE_SKY_SAMPLE && r->sc.sky_density == nullptr) {
+            throw std::runtime_error("probe: no sky distribution (RT_HIP_FLAG_SKY_IMPORTANCE and "
+                                     "an environment map are needed)");
         }
         // every index a probe will follow is checked here, on the host
         for (uint32_t i = 0; i < count; ++i) {
@@ -1800,6 +2073,10 @@ int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per
         *state = r->binning;
         *probe_ns_per_ray = r->probe_ns_per_ray;
     });
+}
+
+int rt_hip_reduce(rt_hip_renderer* const* renderers, uint32_t count) {
+    return guarded([&] { reduce_renderers(renderers, count); });
 }
 
 int rt_hip_destroy(rt_hip_renderer* r) {

@@ -120,9 +120,15 @@ RT_DEV bool propose_light(scene_dev const& sc, uint32_t& seed, f3 ray_direction,
     rt_light const light = sc.lights[rand_uint(seed, 0u, sc.light_count - 1u)];
     ls.type = light.type;
     if (light.type == RT_LIGHT_SKY) {
-        // hemisphere around the incoming ray direction (not the normal), as in the shader
-        f3 const direction = uniform_sample_hemisphere(seed, ray_direction);
+        // hemisphere around the incoming ray direction (not the normal), as in the shader;
+        // with the opt-in tables, a direction drawn in proportion to the map instead
+        bool const importance = sc.sky_density != nullptr && light.emission_tex >= 0;
+        f3 const direction = importance ? sample_sky_importance(sc, seed)
+                                        : uniform_sample_hemisphere(seed, ray_direction);
         f4 const ip = eval_sky_light(sc, direction);
+        if (importance && !(ip.w > 0.0f)) {
+            return false;  // a pole of the map: zero density, nothing to weigh
+        }
         ls.intensity = mk3(ip.x, ip.y, ip.z);
         ls.pdf = light_pdf * ip.w;
         ls.wi = direction;

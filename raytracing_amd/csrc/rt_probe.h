@@ -99,6 +99,14 @@ __global__ void __launch_bounds__(64) probe_kernel(scene_dev const sc, uint32_t 
         r.f[0] = s.x, r.f[1] = s.y, r.f[2] = s.z, r.f[3] = s.w;
         break;
     }
+    case RT_HIP_PROBE_SKY_SAMPLE: {  // the opt-in sky distribution: one draw and its density
+        uint32_t seed = q.u[0];
+        f3 const d = sample_sky_importance(sc, seed);
+        f4 const s = eval_sky_light(sc, d);
+        r.f[0] = d.x, r.f[1] = d.y, r.f[2] = d.z, r.f[3] = s.w;
+        r.u[0] = seed;
+        break;
+    }
     default:
         break;
     }

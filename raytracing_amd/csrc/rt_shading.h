@@ -473,11 +473,57 @@ RT_DEV f4 eval_sky_light(scene_dev const& sc, f3 direction) {
     float const v = theta * kOneOverPi;
     f3 const texel = texture_rgb(sc, sky.emission_tex, u, v);
     f3 const mapped = texel / (texel + splat3(1.0f));  // to_ldr.glsl:1-3
-    float const padded_sin_theta = pad_above_zero(sinf(theta));
-    float const pdf = ((luminance(intensity) / sky.direction[0]) * sky.direction[1] *
-                          sky.direction[2]) /
-                      (kTwoPiPi * padded_sin_theta);
+    float pdf;
+    if (sc.sky_density != nullptr) {
+        // opt-in: the density the direction is actually drawn with (sample_sky_importance)
+        uint32_t const x = min(sc.sky_w - 1u, (uint32_t) (u * (float) sc.sky_w));
+        uint32_t const y = min(sc.sky_h - 1u, (uint32_t) (v * (float) sc.sky_h));
+        float const sin_theta = sinf(theta);
+        pdf = sin_theta > 0.0f ? sc.sky_density[(size_t) y * sc.sky_w + x] / (kTwoPiPi * sin_theta)
+                               : 0.0f;
+    } else {
+        float const padded_sin_theta = pad_above_zero(sinf(theta));
+        pdf = ((luminance(intensity) / sky.direction[0]) * sky.direction[1] * sky.direction[2]) /
+              (kTwoPiPi * padded_sin_theta);
+    }
     return f4{intensity.x * mapped.x, intensity.y * mapped.y, intensity.z * mapped.z, pdf};
+}
+
+// Opt-in replacement of the reference's uniform sky sampling (no counterpart in the shader,
+// whose sample_light draws a uniform direction, megakernel_raytracer.comp:447-457): inverts
+// the piecewise-constant distribution over the map's texels (luminance of the tone-mapped,
+// intensity-scaled texel x sin(theta)), the marginal over rows first, then the row's
+// conditional, with the remainder of each random number placing the sample inside the texel.
+// Two rand_01 draws, like the sampling it replaces.
+RT_DEV float sample_cdf(const float* cdf, uint32_t n, float r) {
+    // largest i in [0, n - 1] with cdf[i] <= r   (cdf has n + 1 entries, cdf[0] = 0, cdf[n] = 1)
+    uint32_t lo = 0, hi = n;
+    while (hi - lo > 1u) {
+        uint32_t const mid = (lo + hi) >> 1;
+        if (cdf[mid] <= r) {
+            lo = mid;
+        } else {
+            hi = mid;
+        }
+    }
+    float const width = cdf[lo + 1u] - cdf[lo];
+    float within = r - cdf[lo];
+    if (width > 0.0f) {
+        within = within / width;
+    }
+    return ((float) lo + fminf(within, 1.0f)) / (float) n;
+}
+
+RT_DEV f3 sample_sky_importance(scene_dev const& sc, uint32_t& seed) {
+    float const r0 = rand_01(seed);
+    float const r1 = rand_01(seed);
+    float const v = sample_cdf(sc.sky_marginal, sc.sky_h, r0);
+    uint32_t const row = min(sc.sky_h - 1u, (uint32_t) (v * (float) sc.sky_h));
+    float const u = sample_cdf(sc.sky_conditional + (size_t) row * (sc.sky_w + 1u), sc.sky_w, r1);
+    float const theta = v * kPi;
+    float const phi = u * kTwoPi - kPi;
+    float const sin_theta = sinf(theta);
+    return mk3(sin_theta * cosf(phi), cosf(theta), sin_theta * sinf(phi));
 }
 
 }  // namespace rtd

@@ -54,14 +54,23 @@ struct slab_ray {
     f3 oinv;  // -origin * inv   (t = plane * inv + oinv)
 };
 
+// A direction component of exactly zero gets a huge FINITE reciprocal: with 1/0 = inf the
+// two plane distances of that axis become inf - inf = NaN for one plane and +-inf for the other
+// whenever the planes lie on different sides of zero, and the box is lost although the ray runs
+// inside the slab.  With 1e18 both distances are finite and of opposite sign (inside the slab:
+// no constraint) or of the same sign and far beyond any scene (outside: a miss).
+RT_DEV float slab_reciprocal(float d) {
+    return d == 0.0f ? copysignf(1.0e18f, d) : 1.0f / d;
+}
+
 RT_DEV slab_ray make_slab_ray(f3 o, f3 d) {
     slab_ray r;
-    r.inv = splat3(1.0f) / d;
+    r.inv = mk3(slab_reciprocal(d.x), slab_reciprocal(d.y), slab_reciprocal(d.z));
     r.oinv = mk3(-o.x * r.inv.x, -o.y * r.inv.y, -o.z * r.inv.z);
     return r;
 }
 
-// Entry/exit distances of one box.  NaNs from 0*inf drop out of fmin/fmax.
+// Entry/exit distances of one box (the reciprocals are finite, see slab_reciprocal).
 RT_DEV void slab_box(slab_ray const& r, float lox, float loy, float loz, float hix, float hiy,
     float hiz, float t_max, float& t_enter, float& t_exit) {
     float const ax = __builtin_fmaf(lox, r.inv.x, r.oinv.x);

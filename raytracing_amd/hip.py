@@ -21,6 +21,7 @@ FLAG_FUSED = 2
 FLAG_TIME_KERNELS = 4
 FLAG_BIN_RAYS = 8
 FLAG_NO_BIN_RAYS = 16
+FLAG_SKY_IMPORTANCE = 32
 BINNING_UNDECIDED, BINNING_OFF, BINNING_ON = 0, 1, 2
 KERNEL_RENDER, KERNEL_EXTEND, KERNEL_SHADE = 0, 1, 2
 MISS = 0xFFFFFFFF
@@ -31,7 +32,7 @@ EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
     "rt_hip_render", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_probe", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
-    "rt_hip_set_passes",
+    "rt_hip_set_passes", "rt_hip_reduce",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
     "rt_hip_trace_work", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
 ]
@@ -51,7 +52,8 @@ class TraceWork(C.Structure):
 
 
 PROBE_RAND01, PROBE_HASH_COMBINE, PROBE_RAND_UINT, PROBE_HIT_AABB, PROBE_HIT_TRIANGLE, \
-    PROBE_EVAL_DISNEY, PROBE_SAMPLE_DISNEY, PROBE_SAMPLE_TEXTURE, PROBE_SKY = range(9)
+    PROBE_EVAL_DISNEY, PROBE_SAMPLE_DISNEY, PROBE_SAMPLE_TEXTURE, PROBE_SKY, \
+    PROBE_SKY_SAMPLE = range(10)
 
 
 class ProbeIn(C.Structure):
@@ -101,6 +103,7 @@ def lib():
         l.rt_hip_accum_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
         l.rt_hip_passes.argtypes = [C.c_void_p, u32p]
         l.rt_hip_set_passes.argtypes = [C.c_void_p, C.c_uint32]
+        l.rt_hip_reduce.argtypes = [C.POINTER(C.c_void_p), C.c_uint32]
         l.rt_hip_stats.argtypes = [C.c_void_p, C.POINTER(T.Stats), C.c_int]
         l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
         l.rt_hip_kernel_time_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), u32p]
@@ -250,3 +253,10 @@ class HipRenderer:
             self.close()
         except Exception:
             pass
+
+
+def reduce(renderers):
+    """rt_hip_reduce: sums the accumulators of `renderers` onto renderers[0] (RCCL between
+    GPUs, a kernel within one) and clears the others."""
+    handles = (C.c_void_p * len(renderers))(*[r._h.value for r in renderers])
+    _check(lib().rt_hip_reduce(handles, len(renderers)))

@@ -3,6 +3,7 @@
 // are idempotent, like the Vulkan back end they replace
 // (src/renderer/megakernel_raytracer.cpp:46, 525-529, 793-797).  Violations
 // terminate, as the reference's CHECK does (src/check.h:10-17).
+#include <algorithm>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -17,7 +18,12 @@ namespace {
 bool initialized = false;
 hip_raytracer_settings settings{};
 render_options options{};
+// One renderer per GPU.  handles[0] (`handle`) owns the image: the tile-by-tile cadence and
+// the preview run on it alone; batched render() calls split their passes over all of them and
+// the accumulators are summed onto it when the image or the pass count is read.
+std::vector<rt_hip_renderer*> handles;
 rt_hip_renderer* handle = nullptr;
+bool reduce_pending = false;
 std::mt19937 seed_source{};
 uint32_t tiles_x = 0, tiles_y = 0;
 uint32_t tile_x = 0, tile_y = 0;  // the reference's tiles.current
@@ -75,10 +81,34 @@ void hip_initialize(render_options const& opts) {
     cfg.max_depth = opts.max_depth;
     cfg.tile_width = opts.tile_width;
     cfg.tile_height = opts.tile_height;
-    cfg.device = settings.device;
     cfg.accel = settings.reference_order ? RT_HIP_ACCEL_REFERENCE : RT_HIP_ACCEL_REBUILT;
     cfg.flags = 0;
-    check(rt_hip_create(&cfg, &handle), "create");
+    std::vector<int> devices = settings.devices;
+    if (devices.empty()) {
+        devices.push_back(settings.device);
+    }
+    for (int device : devices) {
+        cfg.device = device;
+        rt_hip_renderer* h = nullptr;
+        check(rt_hip_create(&cfg, &h), "create");
+        handles.push_back(h);
+    }
+    handle = handles.front();
+    reduce_pending = false;
+}
+
+// Passes [first, first + count) of rank `rank` of `world`: contiguous and balanced.
+void pass_share(uint32_t total, uint32_t world, uint32_t rank, uint32_t& first, uint32_t& count) {
+    uint32_t const base = total / world, extra = total % world;
+    first = rank * base + std::min(rank, extra);
+    count = base + (rank < extra ? 1u : 0u);
+}
+
+void reduce_if_pending() {
+    if (reduce_pending) {
+        check(rt_hip_reduce(handles.data(), (uint32_t) handles.size()), "reduce");
+        reduce_pending = false;
+    }
 }
 
 void hip_prepare_data(scene const& sc) {
@@ -126,8 +156,10 @@ void hip_prepare_data(scene const& sc) {
     d.texture_count = (uint32_t) textures.size();
     d.sky_light =
         sc.lights.back().type == RT_LIGHT_SKY ? (int32_t) sc.lights.size() - 1 : -1;
-    check(rt_hip_upload_scene(handle, &d), "upload_scene");
-    check(rt_hip_clear(handle, nullptr, nullptr), "clear");
+    for (rt_hip_renderer* h : handles) {
+        check(rt_hip_upload_scene(h, &d), "upload_scene");
+        check(rt_hip_clear(h, nullptr, nullptr), "clear");
+    }
 }
 
 void hip_update_data(scene const&) {
@@ -138,6 +170,10 @@ void hip_render(camera const& cam) {
         // :600-619: restart accumulation, show a 1/10-resolution single-sample preview
         tile_x = tile_y = 0;
         passes_requested = 0;
+        reduce_pending = false;  // whatever the other GPUs hold is discarded with the image
+        for (size_t k = 1; k < handles.size(); ++k) {
+            check(rt_hip_clear(handles[k], nullptr, nullptr), "clear");
+        }
         rt_camera const pc = get_glsl_raytracer_camera(
             cam, std::max(1u, options.resolution_x / 10), std::max(1u, options.resolution_y / 10));
         check(rt_hip_render_preview(handle, &pc, next_random_seed(), nullptr), "render_preview");
@@ -150,14 +186,30 @@ void hip_render(camera const& cam) {
         // tile-by-tile cadence would draw them, so both forms give the same image.
         uint32_t const n = settings.passes_per_render;
         if (passes_requested == 0) {
-            check(rt_hip_clear(handle, nullptr, nullptr), "clear");
+            for (rt_hip_renderer* h : handles) {
+                check(rt_hip_clear(h, nullptr, nullptr), "clear");
+            }
         }
         std::vector<uint32_t> seeds((size_t) n * tiles_x * tiles_y);
         for (uint32_t& s : seeds) {
             s = next_random_seed();
         }
-        check(rt_hip_upload_seeds(handle, seeds.data(), passes_requested, n), "upload_seeds");
-        check(rt_hip_render(handle, &rc, passes_requested, n, nullptr, nullptr, nullptr), "render");
+        // every GPU gets the whole call's seed words and traces its own range of the passes:
+        // the launches are asynchronous, so the GPUs work side by side
+        uint32_t const world = (uint32_t) handles.size();
+        for (uint32_t k = 0; k < world; ++k) {
+            uint32_t first = 0, count = 0;
+            pass_share(n, world, k, first, count);
+            if (count == 0) {
+                continue;
+            }
+            check(rt_hip_upload_seeds(handles[k], seeds.data(), passes_requested, n),
+                "upload_seeds");
+            check(rt_hip_render(handles[k], &rc, passes_requested + first, count, nullptr, nullptr,
+                      nullptr),
+                "render");
+        }
+        reduce_pending = world > 1;
         passes_requested += n;
         return;
     }
@@ -180,7 +232,10 @@ void hip_destroy() {
         return;
     }
     initialized = false;
-    check(rt_hip_destroy(handle), "destroy");
+    for (rt_hip_renderer* h : handles) {
+        check(rt_hip_destroy(h), "destroy");
+    }
+    handles.clear();
     handle = nullptr;
 }
 
@@ -200,12 +255,14 @@ void configure_hip_raytracer(hip_raytracer_settings const& s) {
 }
 
 uint32_t hip_raytracer_passes() {
+    reduce_if_pending();
     uint32_t passes = 0;
     check(rt_hip_passes(handle, &passes), "passes");
     return passes;
 }
 
 std::vector<float> hip_raytracer_read_accumulation() {
+    reduce_if_pending();
     std::vector<float> image((size_t) options.resolution_x * options.resolution_y * 4);
     check(rt_hip_read_accum(handle, image.data(), nullptr, nullptr), "read_accum");
     return image;

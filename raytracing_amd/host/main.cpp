@@ -14,7 +14,11 @@
 //       [--reference-order]  traverse the host BVH in the shader's order
 //       [--batch N]          trace N whole passes per render() call
 //       [--device D]         HIP device ordinal
+//       [--devices A,B,...]  several GPUs: with --batch, every render() call splits its
+//                            passes over them (scene replicated per GPU) and the
+//                            accumulators are summed with one RCCL reduce at the end
 //       [--preview-first]    start with camera.dirty = true (exercises the preview path)
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -57,6 +61,16 @@ int main(int argc, char* argv[]) {
             settings.passes_per_render = (uint32_t) std::strtoul(value(), nullptr, 0);
         } else if (a == "--device") {
             settings.device = std::atoi(value());
+        } else if (a == "--devices") {
+            std::string const list = value();
+            size_t at = 0;
+            while (at <= list.size()) {
+                size_t const comma = std::min(list.find(',', at), list.size());
+                if (comma > at) {
+                    settings.devices.push_back(std::atoi(list.substr(at, comma - at).c_str()));
+                }
+                at = comma + 1;
+            }
         } else if (a == "--preview-first") {
             preview_first = true;
         } else if (!a.empty() && a[0] != '-' && scene_file.empty()) {
@@ -65,6 +79,11 @@ int main(int argc, char* argv[]) {
             std::fprintf(stderr, "unknown argument %s\n", a.c_str());
             return 2;
         }
+    }
+    if (settings.devices.size() > 1 && settings.passes_per_render == 0) {
+        // the tile-by-tile cadence is one dispatch at a time by definition; several GPUs need
+        // whole passes to share out
+        settings.passes_per_render = 16;
     }
     if (scene_file.empty()) {
         std::fprintf(stderr, "usage: Raytracing <scene.json> [--spp N] [--out image.png]\n");

@@ -29,6 +29,9 @@ void load_hip_raytracer(renderer& renderer);
 // Additive controls of the HIP back end (the table itself is unchanged).
 struct hip_raytracer_settings {
     int device = -1;              // HIP device ordinal, -1 = current
+    std::vector<int> devices;     // more than one GPU: the batched render() calls split
+                                  // their passes over these (scene replicated, one RCCL
+                                  // sum-reduce when the image is read); overrides `device`
     bool reference_order = false; // walk the host BVH in the shader's order (exact ids)
     bool fixed_seed = true;       // mt19937(seed) instead of mt19937(random_device)
     uint32_t seed = 0x5EED;

@@ -83,6 +83,49 @@ def test_two_rank_gloo_render_equals_single_rank(tmp_path, cornell):
     assert not np.allclose(half, single, rtol=1e-3, atol=1e-3)
 
 
+def test_four_rank_gloo_render_with_an_uneven_pass_count(tmp_path, cornell):
+    """7 passes over 4 ranks: shares of 2, 2, 2 and 1.  The union must be the single-rank
+    render, alpha included."""
+    import oracle
+    from raytracing_amd import host
+    total, world = 7, 4
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    ranges = [tuple(int(v) for v in np.load(tmp_path / f"range_{r}.npy")) for r in range(world)]
+    assert ranges == [(0, 2), (2, 2), (4, 2), (6, 1)]
+    reduced = np.load(tmp_path / "reduced.npy")
+    w, h, tile, md = 64, 64, (16, 16), 4
+    seeds = host.seed_schedule(0, total, 16)
+    single, _ = oracle.render(cornell.desc, cornell.camera(w, h), w, h, md, tile, seeds)
+    assert (reduced[..., 3] == 1.0).all()
+    assert np.allclose(reduced, single, rtol=2e-6, atol=1e-6)
+
+
+def _subgroup_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    group = dist.new_group([1, 2])   # global ranks 1 and 2; group ranks 0 and 1
+    accum = rd.new_accumulator(2, 2, "cpu")
+    accum[..., :3] = float(rank + 1)
+    if rank in (1, 2):
+        rd.reduce_accumulator(accum, dst=2, group=group)   # dst is the GLOBAL rank
+    np.save(os.path.join(out_dir, f"sub_{rank}.npy"), accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_onto_a_global_rank_of_a_subgroup(tmp_path):
+    """dst names a global rank also when a sub-group reduces: the alpha reset must land on
+    global rank 2 (group rank 1), not on the rank whose group rank happens to equal dst."""
+    port = _free_port()
+    mp.spawn(_subgroup_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    on_dst = np.load(tmp_path / "sub_2.npy")
+    assert (on_dst[..., :3] == 2.0 + 3.0).all() and (on_dst[..., 3] == 1.0).all()
+    untouched = np.load(tmp_path / "sub_0.npy")
+    assert (untouched[..., :3] == 1.0).all()
+
+
 def test_reduce_is_identity_without_a_process_group():
     accum = rd.new_accumulator(4, 4, "cpu")
     accum[..., :3] = 2.0

