@@ -799,7 +799,7 @@ void init_launch_plan(rt_hip_renderer& r) {
     }
     // two workgroups of four waves per CU (the kernel's registers allow two waves per
     // SIMD), each with its own LDS copy of the scene's small tables
-    r.wf_shade_grid = cus * 2u;
+    r.wf_shade_grid = cus * kShadeGroupsPerCu;
     r.wf_finish_grid = cus * 8u;  // one-wave workgroups, two per SIMD
     r.wf_bin_groups = cus;
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_count_kernel),

@@ -698,11 +698,19 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
 // (plan_shade_tables) and points its copy of the scene description at them, so the shading
 // code reads them through the same pointers either way.
 constexpr uint32_t kShadeThreads = 256;
-constexpr uint32_t kShadeLdsBudget = 64u * 1024u;
 
 // FIRST: trip 0 - the live paths are pids 0 .. paths-1 with their initial state.
+#ifndef RT_SHADE_WAVES_PER_SIMD
+#define RT_SHADE_WAVES_PER_SIMD 2
+#endif
+// one four-wave workgroup per wave slot of the SIMDs; the workgroups of a CU share its LDS
+#ifndef RT_SHADE_GROUPS_PER_CU
+#define RT_SHADE_GROUPS_PER_CU RT_SHADE_WAVES_PER_SIMD
+#endif
+constexpr uint32_t kShadeGroupsPerCu = RT_SHADE_GROUPS_PER_CU;
+constexpr uint32_t kShadeLdsBudget = (kShadeGroupsPerCu <= 2u ? 64u : 48u) * 1024u;
 template <bool FIRST>
-__global__ void __launch_bounds__(kShadeThreads, 2)
+__global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
     wf_shade_kernel(wavefront_params const p, uint32_t trip) {
     extern __shared__ float4 shade_lds[];
     uint32_t const n_live =

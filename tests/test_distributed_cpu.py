@@ -126,6 +126,59 @@ def test_reduce_onto_a_global_rank_of_a_subgroup(tmp_path):
     assert (untouched[..., :3] == 1.0).all()
 
 
+def test_tile_share_deals_every_tile_once():
+    for tiles_x, tiles_y, world in ((10, 10, 8), (5, 3, 4), (2, 2, 8), (7, 1, 3)):
+        seen = []
+        for rank in range(world):
+            seen += rd.tile_share(tiles_x, tiles_y, world, rank)
+        assert sorted(seen) == sorted((x, y) for y in range(tiles_y) for x in range(tiles_x))
+    with pytest.raises(ValueError):
+        rd.tile_share(4, 4, 2, 2)
+
+
+def _tile_worker(rank, world, port, total_passes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "2"
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from raytracing_amd import host, scenes
+    sc = scenes.load_snapshot("cornell_box")
+    w, h, tile, md = 80, 48, (16, 16), 4     # 5 x 3 = 15 tiles over 4 ranks: 4, 4, 4, 3
+    cam = sc.camera(w, h)
+    seeds = host.seed_schedule(0, total_passes, 15)
+
+    def render_rect(rect, first, count, accum):
+        oracle.render(sc.desc, cam, w, h, md, tile, seeds[first:first + count],
+                      accum=accum.numpy(), first_pass=first, threads=2, rect=rect)
+
+    accum = rd.new_accumulator(h, w, "cpu")
+    mine = rd.render_tile_split(render_rect, total_passes, accum, tile)
+    np.save(os.path.join(out_dir, f"tiles_{rank}.npy"), np.array(mine))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "gathered.npy"), accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_tile_split_is_bit_exact(tmp_path, cornell):
+    """Every pixel is traced by one rank only, so the gathered image equals the single-rank
+    render bit for bit - no float sum changes its order."""
+    import oracle
+    from raytracing_amd import host
+    total, world = 3, 4
+    port = _free_port()
+    mp.spawn(_tile_worker, args=(world, port, total, str(tmp_path)), nprocs=world, join=True)
+    counts = [len(np.load(tmp_path / f"tiles_{r}.npy")) for r in range(world)]
+    assert counts == [4, 4, 4, 3]
+    gathered = np.load(tmp_path / "gathered.npy")
+    w, h, tile, md = 80, 48, (16, 16), 4
+    single, _ = oracle.render(cornell.desc, cornell.camera(w, h), w, h, md, tile,
+                              host.seed_schedule(0, total, 15))
+    assert np.array_equal(gathered, single, equal_nan=True)
+
+
 def test_reduce_is_identity_without_a_process_group():
     accum = rd.new_accumulator(4, 4, "cpu")
     accum[..., :3] = 2.0
