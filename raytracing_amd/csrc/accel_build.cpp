@@ -512,10 +512,23 @@ void set_part_box(tri_part& part, box3 const& within, bool padded) {
 constexpr float kPresplitAboveMedian = 4.0f;  // only boxes this many times the median area
 constexpr uint32_t kPresplitBudgetShift = 3;   // at most triangles / 8 extra references
 
-// The build primitives of one mesh: one per triangle, the largest ones cut into parts.
-void mesh_primitives(rt_scene_desc const& sc, rt_mesh const& mesh, std::vector<build_prim>& prims) {
-    std::vector<tri_part> parts(mesh.triangle_count);
-    std::vector<float> areas(mesh.triangle_count);
+bool mesh_is_all_degenerate(rt_scene_desc const& sc, rt_mesh const& mesh) {
+    for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+        if (!triangle_never_hit(sc.triangles[mesh.triangle_offset + t])) {
+            return false;
+        }
+    }
+    return true;
+}
+
+// The build primitives of one mesh: one per triangle that a ray can hit (all of them when
+// none can: keep_degenerate), the largest ones cut into parts.
+void mesh_primitives(rt_scene_desc const& sc, rt_mesh const& mesh, bool keep_degenerate,
+    std::vector<build_prim>& prims) {
+    std::vector<tri_part> parts;
+    std::vector<float> areas;
+    parts.reserve(mesh.triangle_count);
+    areas.reserve(mesh.triangle_count);
     box3 const everything = [] {
         box3 b;
         for (int a = 0; a < 3; ++a) {
@@ -526,7 +539,10 @@ void mesh_primitives(rt_scene_desc const& sc, rt_mesh const& mesh, std::vector<b
     }();
     for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
         rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
-        tri_part& part = parts[t];
+        if (!keep_degenerate && triangle_never_hit(tri)) {
+            continue;
+        }
+        tri_part part{};
         for (int k = 0; k < 3; ++k) {
             part.poly[0][k] = tri.a.position_texu[k];
             part.poly[1][k] = tri.b.position_texu[k];
@@ -535,20 +551,22 @@ void mesh_primitives(rt_scene_desc const& sc, rt_mesh const& mesh, std::vector<b
         part.corners = 3;
         part.id = mesh.triangle_offset + t;
         set_part_box(part, everything, false);
-        areas[t] = part.box.half_area();
+        areas.push_back(part.box.half_area());
+        parts.push_back(part);
     }
+    uint32_t const listed = (uint32_t) parts.size();
     // RT_HIP_PRESPLIT: tuning knob - 0 disables, another number replaces kPresplitAboveMedian
     char const* const knob = getenv("RT_HIP_PRESPLIT");
     float const above_median = knob ? (float) atof(knob) : kPresplitAboveMedian;
-    uint32_t budget = above_median > 0.0f ? mesh.triangle_count >> kPresplitBudgetShift : 0u;
-    if (budget > 0u && mesh.triangle_count >= 8u) {
+    uint32_t budget = above_median > 0.0f ? listed >> kPresplitBudgetShift : 0u;
+    if (budget > 0u && listed >= 8u) {
         std::nth_element(areas.begin(), areas.begin() + areas.size() / 2, areas.end());
         float const large = above_median * areas[areas.size() / 2];
         auto smaller = [&](uint32_t a, uint32_t b) {
             return parts[a].box.half_area() < parts[b].box.half_area();
         };
         std::vector<uint32_t> heap;
-        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+        for (uint32_t t = 0; t < listed; ++t) {
             if (parts[t].box.half_area() > large) {
                 heap.push_back(t);
             }
@@ -642,6 +660,24 @@ struct tlas_entry {
 };
 
 }  // namespace
+
+bool triangle_never_hit(rt_triangle const& tri) {
+    // hit_triangle (rt_traverse_ref.h): edge1 = b - a, edge2 = c - a,
+    // |cross(edge1, edge2)| < 1e-8 with cross = (a.y b.z - b.y a.z, a.z b.x - b.z a.x,
+    // a.x b.y - b.x a.y) and length = sqrt((x x + y y) + z z), every step rounded to float
+    float const* const a = tri.a.position_texu;
+    float const* const b = tri.b.position_texu;
+    float const* const c = tri.c.position_texu;
+    float const e1x = b[0] - a[0], e1y = b[1] - a[1], e1z = b[2] - a[2];
+    float const e2x = c[0] - a[0], e2y = c[1] - a[1], e2z = c[2] - a[2];
+    float const p0 = e1y * e2z, p1 = e2y * e1z;
+    float const p2 = e1z * e2x, p3 = e2z * e1x;
+    float const p4 = e1x * e2y, p5 = e2x * e1y;
+    float const cx = p0 - p1, cy = p2 - p3, cz = p4 - p5;
+    float const xx = cx * cx, yy = cy * cy, zz = cz * cz;
+    float const sum = (xx + yy) + zz;
+    return std::fabs(std::sqrt(sum)) < 1e-8f;
+}
 
 built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entries) {
     if (sc.instance_count == 0 || sc.mesh_count == 0 || sc.triangle_count == 0) {
@@ -749,7 +785,9 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entrie
     std::vector<int32_t> mesh_root(sc.mesh_count);
     for (uint32_t m = 0; m < sc.mesh_count; ++m) {
         rt_mesh const& mesh = sc.meshes[m];
-        mesh_primitives(sc, mesh, prims);
+        bool const keep_degenerate = mesh_is_all_degenerate(sc, mesh);
+        out.lists_degenerate_triangles = out.lists_degenerate_triangles || keep_degenerate;
+        mesh_primitives(sc, mesh, keep_degenerate, prims);
         auto emit = [&](build_prim const* leaf, uint32_t count) -> uint32_t {
             uint32_t const first = (uint32_t) out.tris.size();
             for (uint32_t i = 0; i < count; ++i) {

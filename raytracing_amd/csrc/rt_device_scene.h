@@ -73,6 +73,7 @@ struct scene_dev {
     const tri_pos* wide_tris;
     const instance_rec* wide_instances;
     int32_t wide_tlas_root;
+    uint32_t wide_lists_degenerate;  // 0: no leaf lists a triangle that hit_triangle's first test rejects
     uint32_t light_count;
     int32_t sky_light;
     // LDS plan of the cached traversal kernel: per-lane stack entries, and how many of the

@@ -1603,6 +1603,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             d.wide_tris = r->upload(accel.tris.data(), accel.tris.size());
             d.wide_instances = r->upload(accel.instances.data(), accel.instances.size());
             d.wide_tlas_root = accel.tlas_root;
+            d.wide_lists_degenerate = accel.lists_degenerate_triangles ? 1u : 0u;
             r->accel_node_bytes = accel.nodes.size() * sizeof(wide_node);
             r->accel_tri_bytes = accel.tris.size() * sizeof(tri_pos);
             r->accel_instance_bytes = accel.instances.size() * sizeof(instance_rec);

@@ -158,31 +158,36 @@ RT_DEV f3 uniform_sample_triangle(uint32_t& seed) {
     return mk3(b0, b1, (1.0f - b0) - b1);
 }
 
-// :35-44
-RT_DEV f3 cosine_sample_hemisphere(uint32_t& seed) {
-    float const r1 = rand_01(seed);
-    float const r2 = rand_01(seed);
+// The point of the unit disk that cosine_sample_hemisphere (:35-44) and sample_ggx_vndf
+// (:46-63) both start from: r = sqrt(r1), phi = 2 pi r2, (r cos phi, r sin phi).  Whichever
+// of the two a lane runs, these are the same operations on the same two random numbers, so
+// sample_disney computes them once for the wave instead of once per divergent branch.
+struct disk_point {
+    float x, y;
+};
+RT_DEV disk_point sample_disk(float r1, float r2) {
     float const r = sqrtf(r1);
     float const phi = kTwoPi * r2;
-    float const x = r * cosf(phi);
-    float const y = r * sinf(phi);
+    return disk_point{r * cosf(phi), r * sinf(phi)};
+}
+
+// :35-44
+RT_DEV f3 cosine_sample_hemisphere(disk_point d) {
+    float const x = d.x;
+    float const y = d.y;
     float const z = sqrtf(fmaxf(0.0f, (1.0f - x * x) - y * y));
     return mk3(x, y, z);
 }
 
 // :46-63 (Heitz 2018 visible-normal sampling)
-RT_DEV f3 sample_ggx_vndf(uint32_t& seed, f3 v, float ax, float ay) {
-    float const r1 = rand_01(seed);
-    float const r2 = rand_01(seed);
+RT_DEV f3 sample_ggx_vndf(disk_point d, f3 v, float ax, float ay) {
     f3 const vh = normalize3(mk3(ax * v.x, ay * v.y, v.z));
     float const lensq = vh.x * vh.x + vh.y * vh.y;
     f3 const t1v = lensq > 0.0f ? mk3(-vh.y, vh.x, 0.0f) * (1.0f / sqrtf(lensq)) :
                                   mk3(1.0f, 0.0f, 0.0f);
     f3 const t2v = cross3(vh, t1v);
-    float const r = sqrtf(r1);
-    float const phi = kTwoPi * r2;
-    float const t1 = r * cosf(phi);
-    float t2 = r * sinf(phi);
+    float const t1 = d.x;
+    float t2 = d.y;
     float const s = 0.5f * (1.0f + vh.z);
     t2 = (1.0f - s) * sqrtf(1.0f - t1 * t1) + s * t2;
     f3 const nh =
@@ -191,9 +196,7 @@ RT_DEV f3 sample_ggx_vndf(uint32_t& seed, f3 v, float ax, float ay) {
 }
 
 // :65-77
-RT_DEV f3 sample_gtr1(uint32_t& seed, float roughness) {
-    float const r1 = rand_01(seed);
-    float const r2 = rand_01(seed);
+RT_DEV f3 sample_gtr1(float r1, float r2, float roughness) {
     float const a = fmaxf(0.001f, roughness);
     float const a2 = a * a;
     float const phi = r1 * kTwoPi;
@@ -432,11 +435,18 @@ RT_DEV f3 sample_disney(uint32_t& seed, hit_state const& st, surface const& si,
     float const cdf2 = cdf1 + lm.metal_pr;
     float const cdf3 = cdf2 + lm.glass_pr;
     float const pr = rand_01(seed);
+    // every lobe's sampler draws exactly two more numbers before anything else
+    float const r1 = rand_01(seed);
+    float const r2 = rand_01(seed);
+    disk_point disk{0.0f, 0.0f};
+    if (pr < cdf3) {
+        disk = sample_disk(r1, r2);
+    }
     f3 l;
     if (pr < cdf0) {
-        l = cosine_sample_hemisphere(seed);
+        l = cosine_sample_hemisphere(disk);
     } else if (pr < cdf3) {
-        f3 h = sample_ggx_vndf(seed, v, si.ax, si.ay);
+        f3 h = sample_ggx_vndf(disk, v, si.ax, si.ay);
         if (h.z < 0.0f) {
             h = -h;
         }
@@ -448,7 +458,7 @@ RT_DEV f3 sample_disney(uint32_t& seed, hit_state const& st, surface const& si,
         }
         l = do_reflect ? normalize3(reflect3(-v, h)) : normalize3(refract3(-v, h, si.eta));
     } else {
-        f3 h = sample_gtr1(seed, si.clearcoat_gloss);
+        f3 h = sample_gtr1(r1, r2, si.clearcoat_gloss);
         if (h.z < 0.0f) {
             h = -h;
         }

@@ -82,8 +82,10 @@ RT_DEV void slab_box(slab_ray const& r, float lox, float loy, float loz, float h
     float const nx = fminf(ax, bx), fx = fmaxf(ax, bx);
     float const ny = fminf(ay, by), fy = fmaxf(ay, by);
     float const nz = fminf(az, bz), fz = fmaxf(az, bz);
-    t_enter = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f)) * 0.99999976f;
-    t_exit = fminf(fminf(fx, fy), fminf(fz, t_max)) * 1.0000002f;
+    // widened by 4 ulp in all (rounding may add candidates, never lose the true hit); the whole
+    // margin sits on the exit side, so the entry distance is also the children's sort key as is
+    t_enter = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
+    t_exit = fminf(fminf(fx, fy), fminf(fz, t_max)) * 1.0000005f;
 }
 
 // One bounce's ray pair.  The occlusion ray (if any) is traced first over
@@ -243,7 +245,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                     }
                     float b0, b1, b2, th;
                     if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
-                            mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th)) {
+                            mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th,
+                            sc.wide_lists_degenerate != 0u)) {
                         if (ANY) {
                             return true;
                         }
@@ -408,7 +411,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             }
             float b0, b1, b2, th;
             if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z), mk3(vc.x, vc.y, vc.z),
-                    tr, t_max, b0, b1, b2, th)) {
+                    tr, t_max, b0, b1, b2, th, sc.wide_lists_degenerate != 0u)) {
                 if (ANY) {
                     return true;
                 }

@@ -87,12 +87,17 @@ RT_DEV tri_ray make_tri_ray(f3 origin, f3 direction) {
 // shaders/raytracer/ray.glsl:119-183 (and :47-105, which is the same test
 // without the outputs).  Accepts 0 < t <= t_max, so a later hit at the same t
 // replaces an earlier one.
+// check_degenerate = false: the caller knows the triangle passes the shader's first test
+// (|cross(edge1, edge2)| >= 1e-8, which does not depend on the ray): the rebuilt structure
+// leaves the triangles that fail it out of its leaves when it is built.
 RT_DEV bool hit_triangle(f3 a, f3 b, f3 c, tri_ray const& ray, float t_max, float& b0,
-    float& b1, float& b2, float& t) {
-    f3 const edge1 = b - a;
-    f3 const edge2 = c - a;
-    if (fabsf(length3(cross3(edge1, edge2))) < 1e-8f) {
-        return false;
+    float& b1, float& b2, float& t, bool check_degenerate = true) {
+    if (check_degenerate) {
+        f3 const edge1 = b - a;
+        f3 const edge2 = c - a;
+        if (fabsf(length3(cross3(edge1, edge2))) < 1e-8f) {
+            return false;
+        }
     }
     f3 const at0 = a - ray.origin;
     f3 const bt0 = b - ray.origin;

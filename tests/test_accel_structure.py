@@ -82,11 +82,15 @@ def test_large_triangles_are_cut_into_parts():
     RT_HIP_PRESPLIT=0 switches the cutting off."""
     def listings(line):
         triangles = int(line.split(" triangles listed ")[0].split()[-1])
-        return triangles, int(line.split(" triangles listed ")[1].split()[0])
+        listed = int(line.split(" triangles listed ")[1].split()[0])
+        # triangles the reference's intersection test rejects for every ray (edge cross product
+        # shorter than 1e-8, ray.glsl:124-128) are left out of the leaves
+        left_out = int(line.split(" triangles no ray can hit left out")[0].split()[-1])
+        return triangles - left_out, listed
 
     paths = [scenes.snapshot_path(n) for n in ("staircase_reduced", "teapot_standin")]
     stair, teapot = map(listings, run_tool(paths))
-    assert stair[0] == 88433 and stair[0] * 1.03 < stair[1] <= stair[0] * 1.125 + 20
+    assert stair[0] == 88433 - 21 and stair[0] * 1.03 < stair[1] <= stair[0] * 1.125 + 20
     assert teapot[1] == teapot[0]
     plain, _ = map(listings, run_tool(paths, env={"RT_HIP_PRESPLIT": "0"}))
     assert plain[1] == plain[0]

@@ -233,9 +233,15 @@ void validate(char const* path) {
                 ++seen[t - mesh.triangle_offset];
             }
         }
-        for (int n : seen) {
-            if (n < 1) {
+        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+            // triangles no ray can hit are left out on purpose (accel_build.h)
+            bool const left_out = !acc.lists_degenerate_triangles &&
+                                  rtd::triangle_never_hit(sc.triangles[mesh.triangle_offset + t]);
+            if (seen[t] < 1 && !left_out) {
                 fail("triangle in no leaf of its instance");
+            }
+            if (seen[t] > 0 && left_out) {
+                fail("a triangle no ray can hit is listed in a leaf");
             }
         }
         if (i % stride != 0) {
@@ -246,6 +252,9 @@ void validate(char const* path) {
             {0.5, 0.0, 0.5}};
         for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
             rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
+            if (!acc.lists_degenerate_triangles && rtd::triangle_never_hit(tri)) {
+                continue;
+            }
             for (auto const& w : weights) {
                 double object[3], world[3];
                 for (int k = 0; k < 3; ++k) {
@@ -276,10 +285,16 @@ void validate(char const* path) {
         fail("stack bound " + std::to_string(acc.max_stack_bound) + " but walks need " +
              std::to_string(need));
     }
+    uint32_t never_hit = 0;
+    for (uint32_t t = 0; t < sc.triangle_count; ++t) {
+        never_hit += rtd::triangle_never_hit(sc.triangles[t]) ? 1u : 0u;
+    }
     printf("%s: ok - %zu nodes (%zu reachable), %u triangles listed %zu times, %u instances in "
-           "%zu TLAS leaves, %zu points found, stack bound %u (TLAS %u, BLAS %u)\n",
+           "%zu TLAS leaves, %zu points found, stack bound %u (TLAS %u, BLAS %u), %u triangles "
+           "no ray can hit %s\n",
         path, acc.nodes.size(), reached, sc.triangle_count, acc.tris.size(), sc.instance_count,
-        acc.instances.size(), points, need, need_tlas, need_blas);
+        acc.instances.size(), points, need, need_tlas, need_blas, never_hit,
+        acc.lists_degenerate_triangles ? "kept" : "left out");
     rt_host_free_scene(scene);
 }
 
