@@ -376,6 +376,7 @@ def main():
                             "instance_records": work["instance_records"] / max(rays_l, 1),
                             "bytes": bytes_call / max(rays_l, 1)},
                 "rays_per_launch": rays_l / launches_per_call,
+                "deepest_traversal_stack": cst["max_stack"],
                 "node_fetches_served_from_lds": lds_share,
                 "memory_served_gbs": memory_bytes_l / (ms * 1e-3) / 1e9,
                 "lds_served_gbs": work["nodes_from_lds"] * NODE_BYTES / launches_per_call

@@ -708,7 +708,16 @@ constexpr uint32_t kShadeThreads = 256;
 #define RT_SHADE_GROUPS_PER_CU RT_SHADE_WAVES_PER_SIMD
 #endif
 constexpr uint32_t kShadeGroupsPerCu = RT_SHADE_GROUPS_PER_CU;
-constexpr uint32_t kShadeLdsBudget = (kShadeGroupsPerCu <= 2u ? 64u : 48u) * 1024u;
+// A wave regroups the paths of this many chunks at a time by what shading them costs (see the
+// kernel); its two lists and the results take 8 bytes of LDS per slot.
+#ifndef RT_SHADE_SPAN_CHUNKS
+#define RT_SHADE_SPAN_CHUNKS 8
+#endif
+constexpr uint32_t kSpanChunks = RT_SHADE_SPAN_CHUNKS;
+constexpr uint32_t kSpanSlots = kSpanChunks * 64u;
+constexpr uint32_t kShadeRegroupLds = (kShadeThreads / 64u) * kSpanSlots * 8u;
+constexpr uint32_t kShadeLdsBudget =
+    (kShadeGroupsPerCu <= 2u ? 80u : 53u) * 1024u - kShadeRegroupLds;
 template <bool FIRST>
 __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
     wf_shade_kernel(wavefront_params const p, uint32_t trip) {
@@ -750,89 +759,164 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
     }
     const uint32_t* const live = p.live;
     uint32_t total_hits = 0, total_skipped = 0, samples = 0;
-    for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
-        uint32_t const i = chunk * 64u + wave_lane();
-        bool const in_range = i < n_live;
-        bool active = in_range;
-        uint32_t const entry = FIRST ? (i | kLiveHasClosest) : (active ? live[i] : 0u);
-        uint32_t const pid = entry & kLivePidMask;
-        ray_pair rp;
-        rp.has_shadow = (entry & kLiveHasShadow) != 0u;
-        rp.has_closest = (entry & kLiveHasClosest) != 0u;
-        uint32_t closest_hits = 0, shadow_skipped = 0;
-        path_state ps;
-        if (FIRST) {
-            active = primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
-            ps.radiance = splat3(0.0f);
-            ps.throughput = splat3(1.0f);
-            ps.nee = splat3(0.0f);
-            ps.last_bsdf_pdf = 0.0f;
-            ps.depth = 0;
-            samples += active ? 1u : 0u;
-        }
-        if (active) {
-            if (!FIRST) {
-                float4 const rad = p.rad[pid];
-                float4 const thr = p.thr[pid];
-                float4 const nee = p.nee[pid];
-                ps.radiance = mk3(rad.x, rad.y, rad.z);
-                ps.depth = __float_as_uint(rad.w);
-                ps.throughput = mk3(thr.x, thr.y, thr.z);
-                ps.seed = __float_as_uint(thr.w);
-                ps.nee = mk3(nee.x, nee.y, nee.z);
-                ps.last_bsdf_pdf = nee.w;
+    // Regrouping inside the wave.  Shading a path that hit a surface and goes on (light
+    // proposal, BSDF sampling, two BSDF evaluations) costs a few thousand instructions; a path
+    // that missed, hit a light or reached max_depth costs a few dozen.  A wave pays for the
+    // dearest of its 64 lanes, and after the first bounce of an open scene nine paths in ten
+    // are of the cheap kind while nearly every chunk of 64 holds one of the other.  So a wave
+    // takes kSpanChunks chunks at a time, sorts their entries into a cheap and a dear list
+    // (LDS, ballot ranks - no atomics), shades each list 64 entries at a time, and then
+    // publishes the results in the entries' original slots: which lane shades which path has
+    // no influence on any result, and the raw slots and chunk counts come out as before.
+    __shared__ uint16_t s_list[kShadeThreads / 64u][2][kSpanSlots];   // [wave][cheap, dear]
+    __shared__ uint32_t s_result[kShadeThreads / 64u][kSpanSlots];    // [wave][slot of the span]
+    uint16_t(*const list)[kSpanSlots] = s_list[threadIdx.x >> 6];
+    uint32_t* const result = s_result[threadIdx.x >> 6];
+    unsigned long long const below = (1ull << wave_lane()) - 1ull;
+    uint32_t const total_spans = (total_chunks + kSpanChunks - 1u) / kSpanChunks;
+    for (uint32_t span = wave_index(); span < total_spans; span += wave_total()) {
+        uint32_t const first_slot = span * kSpanSlots;
+        // 1. classify
+        uint32_t count[2] = {0u, 0u};
+        for (uint32_t k = 0; k < kSpanChunks; ++k) {
+            uint32_t const local = k * 64u + wave_lane();
+            uint32_t const i = first_slot + local;
+            bool const in_range = i < n_live;
+            bool dear = false;
+            if (in_range) {
+                uint32_t const entry = FIRST ? (i | kLiveHasClosest) : live[i];
+                uint32_t const pid = entry & kLivePidMask;
+                bool traced = (entry & kLiveHasClosest) != 0u;
+                if (FIRST) {
+                    // the padding lanes of partial 8x8 blocks have no path and no hit record
+                    uint32_t x, y, pass;
+                    traced = pid_pixel(p, pid, x, y, pass);
+                }
+                if (traced) {
+                    uint32_t const instance = __float_as_uint(p.hit0[pid].x);
+                    uint32_t const depth = FIRST ? 0u : __float_as_uint(p.rad[pid].w);
+                    dear = instance != RT_HIP_MISS && sc.instances[instance].light < 0 &&
+                           depth != p.max_depth;
+                }
             }
-            pair_result pr;
-            pr.occluded = rp.has_shadow && p.occluded[pid] != 0u;
-            pr.hit = false;
-            if (rp.has_closest) {
+            unsigned long long const dear_mask = __ballot(in_range && dear);
+            unsigned long long const cheap_mask = __ballot(in_range && !dear);
+            if (in_range) {
+                unsigned long long const mine = dear ? dear_mask : cheap_mask;
+                list[dear ? 1 : 0][count[dear ? 1 : 0] + (uint32_t) __builtin_popcountll(mine & below)] =
+                    (uint16_t) local;
+            }
+            count[0] += (uint32_t) __builtin_popcountll(cheap_mask);
+            count[1] += (uint32_t) __builtin_popcountll(dear_mask);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // 2. shade: the cheap groups, then the dear groups
+        uint32_t const cheap_groups = (count[0] + 63u) / 64u;
+        uint32_t const groups = cheap_groups + (count[1] + 63u) / 64u;
+        for (uint32_t g = 0; g < groups; ++g) {
+            uint32_t const which = g < cheap_groups ? 0u : 1u;
+            uint32_t const at = (which ? g - cheap_groups : g) * 64u + wave_lane();
+            bool active = at < count[which];
+            uint32_t const local = active ? list[which][at] : 0u;
+            uint32_t const i = first_slot + local;
+            uint32_t const entry = FIRST ? (i | kLiveHasClosest) : (active ? live[i] : 0u);
+            uint32_t const pid = entry & kLivePidMask;
+            ray_pair rp;
+            rp.has_shadow = (entry & kLiveHasShadow) != 0u;
+            rp.has_closest = (entry & kLiveHasClosest) != 0u;
+            uint32_t closest_hits = 0, shadow_skipped = 0;
+            path_state ps;
+            bool const listed = active;
+            if (FIRST && active) {
+                active = primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
+                ps.radiance = splat3(0.0f);
+                ps.throughput = splat3(1.0f);
+                ps.nee = splat3(0.0f);
+                ps.last_bsdf_pdf = 0.0f;
+                ps.depth = 0;
+                samples += active ? 1u : 0u;
+            }
+            if (active) {
                 if (!FIRST) {
-                    float4 const o = p.ray_o[pid];
-                    float4 const d = p.ray_d[pid];
-                    rp.origin = mk3(o.x, o.y, o.z);
-                    rp.direction = mk3(d.x, d.y, d.z);
+                    float4 const rad = p.rad[pid];
+                    float4 const thr = p.thr[pid];
+                    float4 const nee = p.nee[pid];
+                    ps.radiance = mk3(rad.x, rad.y, rad.z);
+                    ps.depth = __float_as_uint(rad.w);
+                    ps.throughput = mk3(thr.x, thr.y, thr.z);
+                    ps.seed = __float_as_uint(thr.w);
+                    ps.nee = mk3(nee.x, nee.y, nee.z);
+                    ps.last_bsdf_pdf = nee.w;
                 }
-                float4 const h0 = p.hit0[pid];
-                pr.best.instance = __float_as_uint(h0.x);
-                pr.hit = pr.best.instance != RT_HIP_MISS;
-                if (pr.hit) {
-                    float2 const h1 = p.hit1[pid];
-                    pr.best.triangle = __float_as_uint(h0.y);
-                    pr.best.b0 = h0.z;
-                    pr.best.b1 = h0.w;
-                    pr.best.b2 = h1.x;
-                    pr.best.t = h1.y;
+                pair_result pr;
+                pr.occluded = rp.has_shadow && p.occluded[pid] != 0u;
+                pr.hit = false;
+                if (rp.has_closest) {
+                    if (!FIRST) {
+                        float4 const o = p.ray_o[pid];
+                        float4 const d = p.ray_d[pid];
+                        rp.origin = mk3(o.x, o.y, o.z);
+                        rp.direction = mk3(d.x, d.y, d.z);
+                    }
+                    float4 const h0 = p.hit0[pid];
+                    pr.best.instance = __float_as_uint(h0.x);
+                    pr.hit = pr.best.instance != RT_HIP_MISS;
+                    if (pr.hit) {
+                        float2 const h1 = p.hit1[pid];
+                        pr.best.triangle = __float_as_uint(h0.y);
+                        pr.best.b0 = h0.z;
+                        pr.best.b1 = h0.w;
+                        pr.best.b2 = h1.x;
+                        pr.best.t = h1.y;
+                    }
                 }
+                shade_trip(sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
+                p.rad[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
+                    __uint_as_float(ps.depth));
+                if (rp.has_closest || rp.has_shadow) {
+                    p.thr[pid] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z,
+                        __uint_as_float(ps.seed));
+                    p.nee[pid] = make_float4(ps.nee.x, ps.nee.y, ps.nee.z, ps.last_bsdf_pdf);
+                }
+                if (rp.has_closest) {
+                    p.ray_o[pid] = make_float4(rp.origin.x, rp.origin.y, rp.origin.z, 0.0f);
+                    p.ray_d[pid] = make_float4(rp.direction.x, rp.direction.y, rp.direction.z, 0.0f);
+                }
+                if (rp.has_shadow) {
+                    p.sh_o[pid] = make_float4(rp.shadow_origin.x, rp.shadow_origin.y,
+                        rp.shadow_origin.z, rp.shadow_t_max);
+                    p.sh_d[pid] = make_float4(rp.shadow_direction.x, rp.shadow_direction.y,
+                        rp.shadow_direction.z, 0.0f);
+                }
+            } else {
+                rp.has_shadow = false;
+                rp.has_closest = false;
             }
-            shade_trip(sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
-            p.rad[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
-                __uint_as_float(ps.depth));
-            if (rp.has_closest || rp.has_shadow) {
-                p.thr[pid] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z,
-                    __uint_as_float(ps.seed));
-                p.nee[pid] = make_float4(ps.nee.x, ps.nee.y, ps.nee.z, ps.last_bsdf_pdf);
+            if (listed) {
+                bool const goes_on = rp.has_closest || rp.has_shadow;
+                result[local] = goes_on ? (pid | (rp.has_closest ? kLiveHasClosest : 0u) |
+                                              (rp.has_shadow ? kLiveHasShadow : 0u))
+                                        : 0u;
             }
-            if (rp.has_closest) {
-                p.ray_o[pid] = make_float4(rp.origin.x, rp.origin.y, rp.origin.z, 0.0f);
-                p.ray_d[pid] = make_float4(rp.direction.x, rp.direction.y, rp.direction.z, 0.0f);
-            }
-            if (rp.has_shadow) {
-                p.sh_o[pid] = make_float4(rp.shadow_origin.x, rp.shadow_origin.y,
-                    rp.shadow_origin.z, rp.shadow_t_max);
-                p.sh_d[pid] = make_float4(rp.shadow_direction.x, rp.shadow_direction.y,
-                    rp.shadow_direction.z, 0.0f);
-            }
-        } else {
-            rp.has_shadow = false;
-            rp.has_closest = false;
+            total_hits += closest_hits;
+            total_skipped += shadow_skipped;
         }
-        bool const goes_on = rp.has_closest || rp.has_shadow;
-        publish_raw(p, chunk, i, in_range,
-            goes_on ? (pid | (rp.has_closest ? kLiveHasClosest : 0u) |
-                          (rp.has_shadow ? kLiveHasShadow : 0u))
-                    : 0u);
-        total_hits += closest_hits;
-        total_skipped += shadow_skipped;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        // 3. publish, slot by slot as the compaction expects them
+        for (uint32_t k = 0; k < kSpanChunks; ++k) {
+            uint32_t const chunk = span * kSpanChunks + k;
+            if (chunk >= total_chunks) {
+                break;
+            }
+            uint32_t const local = k * 64u + wave_lane();
+            uint32_t const i = first_slot + local;
+            bool const in_range = i < n_live;
+            publish_raw(p, chunk, i, in_range, in_range ? result[local] : 0u);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
     }
     unsigned long long const hits = wave_sum(total_hits);
     unsigned long long const skipped = wave_sum(total_skipped);
