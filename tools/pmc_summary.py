@@ -36,15 +36,27 @@ def main():
             bytes_per_launch[k] = fetch + write
         if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0 and k in (
                 "wf_extend_kernel", "wf_shade_kernel", "path_trace_kernel"):
-            wc = c["SQ_WAVE_CYCLES"]
+            # per-launch averages (some counters are collected in two passes)
+            a = {name: value / launches[k][name] for name, value in c.items()}
+            wc = a["SQ_WAVE_CYCLES"]
+            simds = 1024.0  # 256 CUs x 4
             issue[k] = {
-                "valu_active_of_wave_cycles": c.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
-                "waiting_any_of_wave_cycles": c.get("SQ_WAIT_ANY", 0.0) / wc,
-                "waiting_for_issue_of_wave_cycles": c.get("SQ_WAIT_INST_ANY", 0.0) / wc,
-                "lds_active_of_wave_cycles": c.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
-                "vmem_active_of_wave_cycles": c.get("SQ_ACTIVE_INST_VMEM", 0.0) / wc,
-                "valu_instructions": c.get("SQ_INSTS_VALU", 0.0),
-                "salu_instructions": c.get("SQ_INSTS_SALU", 0.0),
+                # share of a wave's resident time during which one of its VALU instructions
+                # executes; times the resident waves per SIMD = how busy the SIMD's VALU is
+                "valu_active_of_wave_cycles": a.get("SQ_ACTIVE_INST_VALU", 0.0) / wc,
+                "waiting_any_of_wave_cycles": a.get("SQ_WAIT_ANY", 0.0) / wc,
+                "waiting_for_issue_of_wave_cycles": a.get("SQ_WAIT_INST_ANY", 0.0) / wc,
+                "lds_active_of_wave_cycles": a.get("SQ_ACTIVE_INST_LDS", 0.0) / wc,
+                # SQ_ACTIVE_INST_VALU counts 4-cycle units summed over the SIMDs;
+                # GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                "valu_busy_of_kernel_time": (a.get("SQ_ACTIVE_INST_VALU", 0.0) * 4.0 / simds)
+                                            / (a["GRBM_GUI_ACTIVE"] / 8.0)
+                                            if a.get("GRBM_GUI_ACTIVE") else None,
+                "valu_lanes_in_use": a.get("SQ_THREAD_CYCLES_VALU", 0.0)
+                                     / (a["SQ_ACTIVE_INST_VALU"] * 64.0)
+                                     if a.get("SQ_ACTIVE_INST_VALU") else None,
+                "valu_instructions_per_launch": a.get("SQ_INSTS_VALU", 0.0),
+                "salu_instructions_per_launch": a.get("SQ_INSTS_SALU", 0.0),
             }
     entry["source"] = source
     entry["bytes_per_launch"] = bytes_per_launch
