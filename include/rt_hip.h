@@ -128,6 +128,14 @@ int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream);
 int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
     uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream);
 
+/* Optional: allocates now what rt_hip_render would otherwise allocate on its first call (and
+ * grow, with a device synchronisation, whenever a larger call arrives): the pipeline's path
+ * state for calls of up to pass_count passes over rectangles of up to width x height pixels
+ * (140 B per path in flight, at most 2^26 paths; plus the ray-binning buffers unless binning is
+ * forced off).  After it, render calls within that size allocate nothing.  No counterpart in
+ * the reference, whose images and buffers are all created in prepare_data (:269-467). */
+int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t pass_count);
+
 /* rt_hip_render for callers that cannot allocate device memory while they render: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in
  * the reference.  Same arguments, same result bit for bit, but the call allocates nothing,

@@ -409,6 +409,7 @@ struct rt_hip_renderer {
     uint32_t wf_extend_grid = 0, wf_extend_waves = 0, wf_shade_grid = 0;  // workgroups, waves
     uint32_t wf_finish_grid = 0;
     uint32_t wf_stat_waves = 0;       // slots of wf.wave_stats
+    int handover_setting = -1;        // RT_HIP_HANDOVER_BELOW at creation (tuning knob), -1 = default
     wavefront_params noalloc{};       // the same arrays inside this device's scratch array
     uint32_t wf_bin_groups = 0;       // workgroups of the ray binning launches
     bool wf_binned = false;           // the binning buffers exist
@@ -1008,10 +1009,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     };
     // Paths alive below which a batch is handed to the finishing kernel (decided on the
     // device after every compaction): 1 % of the batch, at least a GPU's worth of lanes.
-    static int const handover_setting = [] {
-        char const* v = getenv("RT_HIP_HANDOVER_BELOW");  // tuning knob: absolute path count
-        return v ? atoi(v) : -1;
-    }();
+    int const handover_setting = r.handover_setting;
     auto finish = [&](uint32_t trip, uint32_t chunk_bound) {
         dim3 const grid(std::max(1u, std::min(r.wf_finish_grid, chunk_bound)));
         if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
@@ -1522,6 +1520,9 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         HIP_CHECK(hipEventCreate(&r->probe_done));
         HIP_CHECK(hipEventCreateWithFlags(&r->last_done, hipEventDisableTiming));
         init_launch_plan(*r);
+        if (char const* const v = getenv("RT_HIP_HANDOVER_BELOW")) {
+            r->handover_setting = atoi(v);  // tuning knob: absolute number of live paths
+        }
         r->noalloc = carve_scratch(scratch_base(r->device), r->wf.wave_stats);
         *out = r.release();
     });
@@ -1693,6 +1694,29 @@ int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pa
     return guarded([&] {
         render_passes(r, camera, first_pass, pass_count, rect, accum_dev, (hipStream_t) stream,
             false);
+    });
+}
+
+int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t pass_count) {
+    return guarded([&] {
+        if (!r) {
+            throw std::runtime_error("null renderer");
+        }
+        if (width == 0 || height == 0 || pass_count == 0 || width > r->cfg.width ||
+            height > r->cfg.height) {
+            throw std::runtime_error("reserve: bad size");
+        }
+        if (r->cfg.flags & RT_HIP_FLAG_FUSED) {
+            return;  // the fused kernel keeps its paths in registers
+        }
+        size_t const per_pass = (size_t) ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
+        if (per_pass > kWavefrontMaxPaths) {
+            throw std::runtime_error("reserve: one pass of that rectangle exceeds one batch");
+        }
+        size_t const batch = std::min<size_t>(pass_count, std::max<size_t>(1, kWavefrontMaxPaths / per_pass));
+        device_scope const on_device(r->device);
+        bool const binned = r->binning != RT_HIP_BINNING_OFF;  // decided later: be ready for it
+        ensure_wavefront(*r, per_pass * batch, r->cfg.max_depth + 1u, binned);
     });
 }
 

@@ -30,7 +30,7 @@ NOALLOC_MAX_DEPTH = 63
 
 EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
-    "rt_hip_render", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
+    "rt_hip_render", "rt_hip_reserve", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_probe", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes", "rt_hip_reduce",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
@@ -90,6 +90,7 @@ def lib():
         l.rt_hip_render.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
                                     u32p, C.c_void_p, C.c_void_p]
         l.rt_hip_render_noalloc.argtypes = l.rt_hip_render.argtypes
+        l.rt_hip_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
         l.rt_hip_render_tile.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p]
         l.rt_hip_render_preview.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32,
@@ -146,6 +147,10 @@ class HipRenderer:
         r = (C.c_uint32 * 4)(*rect) if rect is not None else None
         _check(lib().rt_hip_render(self._h, C.byref(camera), first_pass, pass_count, r,
                                    accum_dev, stream))
+
+    def reserve(self, width, height, pass_count):
+        """Allocate the pipeline's path state for calls of that size now (rt_hip_reserve)."""
+        _check(lib().rt_hip_reserve(self._h, width, height, pass_count))
 
     def render_noalloc(self, camera, first_pass, pass_count, rect=None, accum_dev=None,
                        stream=None):

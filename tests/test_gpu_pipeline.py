@@ -183,3 +183,73 @@ def test_trip_counts_and_kernel_times(hyperion):
             r.trip_counts(md + 5)
     finally:
         r.close()
+
+
+def test_one_pass_larger_than_a_batch_is_refused(cornell):
+    """8192 x 8256 pixels = 67.6 M paths per pass, more than the 2^26 one batch holds: the
+    pipeline must refuse the call (it used to truncate its lists silently); the fused kernel,
+    which keeps no lists, still renders it, and so does the pipeline in two halves."""
+    w, h, tile = 8192, 8256, (1024, 1032)
+    r = hip.HipRenderer(w, h, 1, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, 1, r.tile_count))
+        cam = cornell.camera(w, h)
+        r.clear()
+        with pytest.raises(RuntimeError, match="more than the 67108864"):
+            r.render(cam, 0, 1)
+        with pytest.raises(RuntimeError, match="exceeds one batch"):
+            r.reserve(w, h, 1)
+        r.render(cam, 0, 1, rect=(0, 0, w, h // 2))
+        r.render(cam, 0, 1, rect=(0, h // 2, w, h))
+        halves, _ = r.read_accum()
+    finally:
+        r.close()
+    # (an edge-on light sample makes the shader itself produce NaN: a few pixels in 67 M)
+    assert np.isnan(halves).any(axis=2).mean() < 1e-5 and np.nanmax(halves[..., :3]) > 0
+    assert (np.nan_to_num(halves[::517, ::511, :3]).sum(axis=2) > 0).mean() > 0.5
+
+
+def test_reserve_then_render(cornell):
+    w, h, md, tile, spp = 320, 184, 5, (64, 46), 4
+    plain = run(cornell, w, h, md, tile, spp, hip.ACCEL_REBUILT, 0)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.reserve(w, h, spp)
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+        r.clear()
+        r.render(cornell.camera(w, h), 0, spp)
+        img, _ = r.read_accum()
+        with pytest.raises(RuntimeError, match="bad size"):
+            r.reserve(w + 1, h, spp)
+    finally:
+        r.close()
+    assert same(img, plain[0])
+
+
+def test_calls_on_different_streams_of_one_handle_are_ordered(hyperion):
+    """A handle's calls share its path state and counters.  Issued on two different streams
+    back to back (no host synchronisation in between), the second must wait for the first on
+    the device: the image equals the one-stream render bit for bit."""
+    import torch
+    w, h, md, tile = 640, 360, 5, (64, 36)
+    cam = hyperion.camera(w, h)
+    seeds = host.seed_schedule(0, 8, 100)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(seeds)
+        r.clear()
+        r.render(cam, 0, 8)
+        want, _ = r.read_accum()
+        a, b = torch.cuda.Stream(), torch.cuda.Stream()
+        r.clear(stream=a.cuda_stream)
+        for k in range(8):
+            r.render(cam, k, 1, stream=(a if k % 2 == 0 else b).cuda_stream)
+        torch.cuda.synchronize()
+        got, passes = r.read_accum()
+    finally:
+        r.close()
+    assert passes == 8 and same(got, want)
+    assert torch.cuda.current_device() == 0
