@@ -27,6 +27,10 @@ struct surface {
 // centres at +0.5 (sampler: src/vulkan/vulkan_image.cpp:309-330).
 RT_DEV uint32_t wrap_repeat(int i, uint32_t size) {
     int const s = (int) size;
+    if ((size & (size - 1u)) == 0u) {
+        // power-of-two sizes (the usual case): the two's-complement bits are the remainder
+        return (uint32_t) i & (size - 1u);
+    }
     int m = i % s;
     if (m < 0) {
         m += s;
@@ -53,10 +57,12 @@ RT_DEV f4 sample_texture(scene_dev const& sc, int tex, float u, float v) {
     float const fy = floorf(y);
     float const a = x - fx;
     float const b = y - fy;
+    // the neighbour of a wrapped coordinate is its successor, wrapped once more at the edge:
+    // the same texel as wrapping fx + 1 itself, without a second remainder
     uint32_t const x0 = wrap_repeat((int) fx, t.width);
-    uint32_t const x1 = wrap_repeat((int) fx + 1, t.width);
+    uint32_t const x1 = x0 + 1u == t.width ? 0u : x0 + 1u;
     uint32_t const y0 = wrap_repeat((int) fy, t.height);
-    uint32_t const y1 = wrap_repeat((int) fy + 1, t.height);
+    uint32_t const y1 = y0 + 1u == t.height ? 0u : y0 + 1u;
     f4 const t00 = load_texel(t, x0, y0);
     f4 const t10 = load_texel(t, x1, y0);
     f4 const t01 = load_texel(t, x0, y1);
