@@ -4,7 +4,7 @@
  * PARITY UNPINNED in the strict sense: the reference has no tests, known-answer
  * vectors or fixed-seed images and cannot run offline, so no reference-held
  * vector is reproduced bit for bit; this file restates the GLSL literally.
- * What the reference does hold - its two window screenshots, outputs/*.png -
+ * What the reference does hold - the window screenshots in its outputs directory -
  * pins the results statistically: tests/test_oracle_golden.py compares this
  * oracle with outputs/hyperion_rect_light.png in linear radiance (mean within
  * 2 %, block means within the noise of 16 passes), and the HIP path, which is
