@@ -256,7 +256,8 @@ def main():
     r.upload_scene(sc.desc)
 
     spp = args.spp_per_step
-    total_steps = args.warmup + args.steps + 1          # + the untimed set-up call below
+    setup_calls = 3                                     # the untimed set-up calls below
+    total_steps = args.warmup + args.steps + setup_calls
     passes_per_rank = total_steps * spp
     first_pass = rank * passes_per_rank  # global pass index: ranks trace disjoint passes
     seeds = host.seed_schedule(first_pass, passes_per_rank, r.tile_count)
@@ -268,14 +269,20 @@ def main():
     def step(i):
         r.render(cam, first_pass + i * spp, spp, accum_dev=accum.data_ptr(), stream=stream)
 
-    # Set-up call: allocates the pipeline state and, with --binning auto, is the call the library
-    # measures; waiting for it and asking for the verdict settles the binning policy, so every
-    # warm-up and timed step below runs the same configuration.
-    step(0)
-    torch.cuda.synchronize()
-    binning_state, probe_ns = r.ray_binning() if args.pipeline != "fused" else (1, 0.0)
+    # Set-up calls: the first allocates the pipeline state and, with --binning auto, is the call
+    # the library measures for the ray binning; the next two are the ones it times with fixed
+    # chunks and with refilled lanes in the trace launches.  Waiting for each and asking for the
+    # verdict settles both policies, so every warm-up and timed step below runs the same
+    # configuration.
+    binning_state, probe_ns, refill = 1, 0.0, (0, -1.0, -1.0, 0)
+    for i in range(setup_calls):
+        step(i)
+        torch.cuda.synchronize()
+        if args.pipeline != "fused":
+            binning_state, probe_ns = r.ray_binning()
+            refill = r.trace_refill()
     for i in range(args.warmup):
-        step(1 + i)
+        step(setup_calls + i)
     torch.cuda.synchronize()
     r.stats(reset=True)
     accum.zero_()
@@ -286,7 +293,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(1 + args.warmup + i)
+        step(setup_calls + args.warmup + i)
     reduce_accumulator(accum, dst=0)
     torch.cuda.synchronize()
     if world > 1:
@@ -319,6 +326,9 @@ def main():
                 per_call = n // max(launches, 1)
                 extra = {"ray_binning": ["undecided", "off", "on"][binning_state],
                          "ray_binning_probe_ns_per_ray": probe_ns,
+                         "trace_refill": ["undecided", "off", "on"][refill[0]],
+                         "trace_refill_probe_ms": [refill[1], refill[2]],
+                         "trace_refill_bounces": f"{refill[3]:#x}",
                          "trace_launches_per_call": per_call,
                          "render_call_avg_ms": kernel_ms, "render_calls": launches,
                          "shade_kernel_avg_ms": shade_ms, "shade_launches": shade_n,

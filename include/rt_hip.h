@@ -80,6 +80,12 @@ enum {
 };
 
 enum {
+    RT_HIP_REFILL_UNDECIDED = 0, /* not yet measured on this scene: refilling is used meanwhile */
+    RT_HIP_REFILL_OFF = 1,
+    RT_HIP_REFILL_ON = 2
+};
+
+enum {
     RT_HIP_KERNEL_RENDER = 0, /* everything one rt_hip_render* call enqueues */
     RT_HIP_KERNEL_EXTEND = 1, /* one trace launch of the pipeline (one bounce of a batch) */
     RT_HIP_KERNEL_SHADE = 2   /* one shade launch of the pipeline */
@@ -293,6 +299,18 @@ int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out);
  * of whole-GPU time (0 when forced by a flag or not yet measured).  No counterpart in the
  * reference. */
 int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per_ray);
+
+/* Diagnostics of the pipeline: how its trace launches hand out rays on the uploaded scene
+ * (RT_HIP_REFILL_*).  A wave either takes fixed chunks of 64 rays or gives each lane that has
+ * finished its ray the next one (once half its lanes wait); which is faster depends on how
+ * unequal the rays' walks are, so after the ray binning is settled one large render call is
+ * timed in each mode and the faster kept, bounce by bounce (ON = some bounce refills).  ms_off /
+ * ms_on: the summed trace launches of those two calls, -1 until measured.  trip_mask: bit b set
+ * = the trace launch of bounce b refills (bit 31 stands for every later bounce).  Out pointers
+ * other than `state` may be null.  Images are bit-identical either way.  No counterpart in the
+ * reference. */
+int rt_hip_trace_refill(rt_hip_renderer* r, uint32_t* state, double* ms_off, double* ms_on,
+    uint32_t* trip_mask);
 
 /* Replaces megakernel_raytracer_destroy (:793-813). */
 int rt_hip_destroy(rt_hip_renderer* r);

@@ -429,6 +429,196 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     }
 }
 
+// The same walk as trace_fast<.., CACHED = true>, cut into resumable rounds: start() takes a
+// ray, round() runs one round (descend until the lane holds a leaf or has nothing left, then
+// enter the instance or test the leaf's triangles and pop) and says whether the walk is over.
+// A wave that keeps one walk per lane can hand a finished lane its next ray while the other
+// lanes are still walking (wf_extend_kernel).  Same visiting order, same arithmetic.
+template <bool ANY, bool COUNT>
+struct fast_walk {
+    f3 origin, direction;
+    slab_ray world_slab, slab;
+    tri_ray tr;
+    float t_max;
+    hit_result best;
+    uint32_t current_instance;
+    uint32_t sp;
+    int32_t cur;
+    bool in_blas;
+    bool found;
+
+    static constexpr int32_t kDone = (int32_t) 0x80000000u;
+
+    RT_DEV void start(scene_dev const& sc, f3 o, f3 d, float t_limit) {
+        origin = o;
+        direction = d;
+        world_slab = make_slab_ray(o, d);
+        slab = world_slab;
+        tr = make_tri_ray(o, d);
+        t_max = t_limit;
+        found = false;
+        best.instance = RT_HIP_MISS;
+        best.triangle = RT_HIP_MISS;
+        best.b0 = best.b1 = best.b2 = 0.0f;
+        best.t = kInfinity;
+        current_instance = 0;
+        sp = 0;
+        cur = sc.wide_tlas_root;
+        in_blas = false;
+    }
+
+    RT_DEV void push(fast_stack const& stk, trace_counters& cnt, int32_t v) {
+        stk.lds[sp * 64u] = (uint32_t) v;
+        ++sp;
+        if (COUNT) {
+            cnt.max_stack = max(cnt.max_stack, sp);
+        }
+    }
+
+    RT_DEV void next_subtree(fast_stack const& stk) {
+        for (;;) {
+            if (sp == 0) {
+                cur = kDone;
+                return;
+            }
+            --sp;
+            cur = (int32_t) stk.lds[sp * 64u];
+            if (cur != kInstanceMarker) {
+                return;
+            }
+            in_blas = false;
+            slab = world_slab;
+        }
+    }
+
+    RT_DEV void node_step(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
+        float4 lx, ly, lz, hx, hy, hz, kids;
+        if ((uint32_t) cur < stk.cached_nodes) {
+            const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+            lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
+            if (COUNT) {
+                ++cnt.lds_nodes;
+            }
+        } else {
+            const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+            lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
+        }
+        if (COUNT) {
+            ++cnt.nodes;
+        }
+        int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y), __float_as_int(kids.z),
+            __float_as_int(kids.w)};
+        float key[4];
+        float const miss = kInfinity * 2.0f;
+        {
+            float e, x;
+            slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
+            key[0] = e <= x ? e : miss;
+            slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
+            key[1] = e <= x ? e : miss;
+            slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
+            key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
+            slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
+            key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
+        }
+        auto order = [&](int i, int j) {
+            bool const swap = key[j] < key[i];
+            float const ki = swap ? key[j] : key[i];
+            float const kj = swap ? key[i] : key[j];
+            int32_t const ri = swap ? ref[j] : ref[i];
+            int32_t const rj = swap ? ref[i] : ref[j];
+            key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
+        };
+        order(0, 1);
+        order(2, 3);
+        order(0, 2);
+        order(1, 3);
+        order(1, 2);
+        if (key[0] < miss) {
+            if (key[3] < miss) {
+                push(stk, cnt, ref[3]);
+            }
+            if (key[2] < miss) {
+                push(stk, cnt, ref[2]);
+            }
+            if (key[1] < miss) {
+                push(stk, cnt, ref[1]);
+            }
+            cur = ref[0];
+        } else {
+            next_subtree(stk);
+        }
+    }
+
+    // Returns true when the walk is over.
+    RT_DEV bool round(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
+        while (cur >= 0) {
+            node_step(sc, stk, cnt);
+        }
+        if (cur == kDone) {
+            return true;
+        }
+        if (!in_blas) {
+            uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
+            const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+            float4 r0, r1, r2, r3;
+            if (rec_index < stk.cached_instances) {
+                const float4* lp = stk.instance_cache + 4u * rec_index;
+                r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+                if (COUNT) {
+                    ++cnt.lds_instances;
+                }
+            } else {
+                r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
+            }
+            if (COUNT) {
+                ++cnt.instances;
+            }
+            f3 o, d;
+            o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
+            o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
+            o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
+            d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
+            d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
+            d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
+            slab = make_slab_ray(o, d);
+            tr = make_tri_ray(o, d);
+            current_instance = (uint32_t) __float_as_int(r3.y);
+            push(stk, cnt, kInstanceMarker);
+            in_blas = true;
+            cur = __float_as_int(r3.x);
+            return false;
+        }
+        uint32_t const code = (uint32_t) ~cur;
+        uint32_t const first = code >> 3;
+        uint32_t const count = (code & 7u) + 1u;
+        for (uint32_t k = 0; k < count; ++k) {
+            const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+            float4 const va = tp[0], vb = tp[1], vc = tp[2];
+            if (COUNT) {
+                ++cnt.tris;
+            }
+            float b0, b1, b2, th;
+            if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z), mk3(vc.x, vc.y, vc.z),
+                    tr, t_max, b0, b1, b2, th, sc.wide_lists_degenerate != 0u)) {
+                found = true;
+                if (ANY) {
+                    return true;
+                }
+                t_max = th;
+                best.instance = current_instance;
+                best.triangle = (uint32_t) __float_as_int(va.w);
+                best.b0 = b0;
+                best.b1 = b1;
+                best.b2 = b2;
+                best.t = th;
+            }
+        }
+        next_subtree(stk);
+        return false;
+    }
+};
+
 template <bool COUNT>
 RT_DEV void trace_pair_fast(scene_dev const& sc, fast_stack const& stk, ray_pair const& rp,
     pair_result& out, trace_counters& cnt) {

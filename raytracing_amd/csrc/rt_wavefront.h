@@ -95,6 +95,7 @@ struct wavefront_params {
     // ray binning (sort_rays != 0): the queues regrouped by direction octant and origin cell,
     // with the rays copied next to them so that the trace launch reads them in queue order
     uint32_t sort_rays;
+    uint32_t refill;  // trace launches: a wave hands its finished lanes new rays (rebuilt structure)
     float sort_lo[3], sort_scale[3];  // cell = (origin - lo) * scale, clamped to sort_top
     float sort_top[3];                // cells along each axis - 1
     uint32_t sort_shift[3];           // position of each axis' cell index in the bin number
@@ -563,6 +564,17 @@ __global__ void __launch_bounds__(kBinThreads) wf_bin_place_kernel(wavefront_par
 // before it starts) and every wave's traversal stack.  Reference-order structure: one wave
 // per workgroup, private stack, no LDS.
 constexpr uint32_t kExtendThreads = 1024;
+#ifndef RT_PERSISTENT_TRACE
+#define RT_PERSISTENT_TRACE 1
+#endif
+#ifndef RT_REFILL_IDLE
+#define RT_REFILL_IDLE 32
+#endif
+constexpr uint32_t kRefillIdle = RT_REFILL_IDLE;  // lanes that must wait before a wave refills
+#ifndef RT_REFILL_RUN
+#define RT_REFILL_RUN 1
+#endif
+constexpr uint32_t kRefillRun = RT_REFILL_RUN;    // consecutive chunks a wave takes at a time
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 
 // FIRST: trip 0 - the rays are the primary rays of pids 0 .. paths-1, built on the spot.
@@ -608,6 +620,90 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         first_ctl[kCtlLive] = n_closest;
         first_ctl[kCtlClosest] = n_closest;
     }
+#if RT_PERSISTENT_TRACE
+    if (ACCEL == RT_HIP_ACCEL_REBUILT && p.refill != 0u) {
+        // One walk per lane, refilled: the rays of a wave need very different numbers of steps
+        // (the mean over the maximum of 64 is what bounds the lanes in use), so a lane whose
+        // ray is done takes the wave's next ray - but only once at least kRefillIdle lanes
+        // wait, so that the per-ray set-up (six exact divisions) runs on many lanes at once.
+        // A wave takes runs of kRefillRun consecutive chunks (run r of wave w starts at chunk
+        // (w + r W) kRefillRun): rays fetched into the same wave come from neighbouring
+        // chunks - the same or adjacent bins when the queue is binned - and runs are dealt
+        // round robin so that every wave gets work from all over the queue.
+        uint32_t const w = wave_index(), W = wave_total();
+        unsigned long long const below = (1ull << wave_lane()) - 1ull;
+        auto run = [&](auto walk, uint32_t n, auto fetch, auto deliver) {
+            uint32_t const runs = (n + kRefillRun * 64u - 1u) / (kRefillRun * 64u);
+            uint32_t const my_runs = w < runs ? (runs - w + W - 1u) / W : 0u;
+            uint32_t const mine = my_runs * kRefillRun * 64u;  // slots; those past n have no ray
+            uint32_t next = 0;
+            bool busy = false;
+            uint32_t pid = 0;
+            for (;;) {
+                unsigned long long const idle = __ballot(!busy);
+                uint32_t const idle_count = (uint32_t) __builtin_popcountll(idle);
+                if (next < mine && (idle_count >= kRefillIdle || idle_count == 64u)) {
+                    uint32_t const take = min(idle_count, mine - next);
+                    uint32_t const rank = (uint32_t) __builtin_popcountll(idle & below);
+                    if (!busy && rank < take) {
+                        uint32_t const j = next + rank;
+                        uint32_t const run_slots = kRefillRun * 64u;
+                        uint32_t const i = (w + (j / run_slots) * W) * run_slots + j % run_slots;
+                        f3 o, d;
+                        float t_limit;
+                        if (i < n && fetch(i, pid, o, d, t_limit)) {
+                            walk.start(p.sc, o, d, t_limit);
+                            busy = true;
+                        }
+                    }
+                    next += take;
+                    continue;  // (lanes whose slot held no ray try again)
+                }
+                if (idle_count == 64u) {
+                    break;  // nothing walking and nothing left to fetch
+                }
+                if (busy && walk.round(p.sc, stk, cnt)) {
+                    deliver(pid, walk);
+                    busy = false;
+                }
+            }
+        };
+        run(fast_walk<false, COUNT>{}, n_closest,
+            [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
+                t_limit = kInfinity;
+                if (FIRST) {
+                    uint32_t seed;
+                    pid = i;
+                    return primary_of_pid(p, pid, seed, o, d);
+                }
+                pid = stream_load(&q_closest[i]);
+                float4 const ro = stream_load(&p.ray_o[pid]);
+                float4 const rd = stream_load(&p.ray_d[pid]);
+                o = mk3(ro.x, ro.y, ro.z);
+                d = mk3(rd.x, rd.y, rd.z);
+                return true;
+            },
+            [&](uint32_t pid, fast_walk<false, COUNT> const& wk) {
+                stream_store(&p.hit0[pid],
+                    make_float4(__uint_as_float(wk.found ? wk.best.instance : RT_HIP_MISS),
+                        __uint_as_float(wk.best.triangle), wk.best.b0, wk.best.b1));
+                stream_store(&p.hit1[pid], make_float2(wk.best.b2, wk.best.t));
+            });
+        run(fast_walk<true, COUNT>{}, n_shadow,
+            [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
+                pid = stream_load(&q_shadow[i]);
+                float4 const ro = stream_load(&p.sh_o[pid]);
+                float4 const rd = stream_load(&p.sh_d[pid]);
+                o = mk3(ro.x, ro.y, ro.z);
+                d = mk3(rd.x, rd.y, rd.z);
+                t_limit = ro.w;
+                return true;
+            },
+            [&](uint32_t pid, fast_walk<true, COUNT> const& wk) {
+                stream_store(&p.occluded[pid], wk.found ? 1u : 0u);
+            });
+    } else
+#endif
     for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
         if (chunk < closest_chunks) {
             uint32_t const i = chunk * 64u + wave_lane();

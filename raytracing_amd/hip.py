@@ -23,6 +23,7 @@ FLAG_BIN_RAYS = 8
 FLAG_NO_BIN_RAYS = 16
 FLAG_SKY_IMPORTANCE = 32
 BINNING_UNDECIDED, BINNING_OFF, BINNING_ON = 0, 1, 2
+REFILL_UNDECIDED, REFILL_OFF, REFILL_ON = 0, 1, 2
 KERNEL_RENDER, KERNEL_EXTEND, KERNEL_SHADE = 0, 1, 2
 MISS = 0xFFFFFFFF
 NOALLOC_MAX_PATHS = 1 << 18
@@ -34,7 +35,7 @@ EXPORTS = [
     "rt_hip_probe", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes", "rt_hip_reduce",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
-    "rt_hip_trace_work", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
+    "rt_hip_trace_work", "rt_hip_trace_refill", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
 
@@ -111,6 +112,8 @@ def lib():
         l.rt_hip_trip_counts.argtypes = [C.c_void_p, C.c_uint32, u32p]
         l.rt_hip_trace_work.argtypes = [C.c_void_p, C.POINTER(TraceWork)]
         l.rt_hip_ray_binning.argtypes = [C.c_void_p, u32p, C.POINTER(C.c_double)]
+        l.rt_hip_trace_refill.argtypes = [C.c_void_p, u32p, C.POINTER(C.c_double),
+                                          C.POINTER(C.c_double), u32p]
         l.rt_hip_destroy.argtypes = [C.c_void_p]
         _lib = l
     return _lib
@@ -241,6 +244,15 @@ class HipRenderer:
         out = TraceWork()
         _check(lib().rt_hip_trace_work(self._h, C.byref(out)))
         return {name: getattr(out, name) for name, _ in out._fields_}
+
+    def trace_refill(self):
+        """(REFILL_* state, summed trace ms of the call timed without / with refilling, bit mask of
+        the bounces whose trace launch refills)."""
+        state, mask = C.c_uint32(), C.c_uint32()
+        off, on = C.c_double(), C.c_double()
+        _check(lib().rt_hip_trace_refill(self._h, C.byref(state), C.byref(off), C.byref(on),
+                                         C.byref(mask)))
+        return state.value, off.value, on.value, mask.value
 
     def trip_counts(self, trip):
         """(live paths, closest-hit rays, occlusion rays) of bounce `trip` in the last batch."""

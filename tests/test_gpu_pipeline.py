@@ -154,6 +154,64 @@ def test_ray_binning_is_decided_by_measurement(cornell, staircase):
     assert all(state in (hip.BINNING_ON, hip.BINNING_OFF) for state, _ in outcome.values())
 
 
+@pytest.mark.parametrize("refill", ["0", "1"])
+@pytest.mark.parametrize("binning", BINNING)
+def test_trace_launch_hands_out_rays_either_way(monkeypatch, staircase, binning, refill):
+    """The trace launch gives a wave fixed chunks of 64 rays, or gives each lane that has
+    finished its ray the next one.  Either way (forced here through the experiment knob, read
+    when a scene is uploaded) every ray is traced exactly once: image and work counters equal
+    the fused kernel's."""
+    monkeypatch.setenv("RT_HIP_TRACE_REFILL", refill)
+    w, h, md, tile, spp = 320, 184, 7, (64, 46), 5
+    fused = run(staircase, w, h, md, tile, spp, hip.ACCEL_REBUILT,
+                hip.FLAG_FUSED | hip.FLAG_COUNT_NODES)
+    piped = run(staircase, w, h, md, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_COUNT_NODES | binning)
+    assert same(fused[0], piped[0])
+    for k in COUNTERS:
+        assert fused[2][k] == piped[2][k], k
+
+
+def test_trace_refill_is_decided_by_measurement(hyperion):
+    """Once the ray binning is settled, one large call is timed with fixed chunks and one with
+    refilled lanes; the faster way is kept bounce by bounce.  The outcome depends on the clock
+    and is not asserted; the image must not depend on it."""
+    w, h, md, tile, spp = 640, 800, 7, (64, 80), 16
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(host.seed_schedule(0, 4 * spp, r.tile_count))
+        cam = hyperion.camera(w, h)
+        assert r.trace_refill() == (hip.REFILL_UNDECIDED, -1.0, -1.0, 0xFFFFFFFF)
+        r.clear()
+        seen = []
+        for call in range(4):
+            r.render(cam, call * spp, spp)
+            r.read_accum()
+            seen.append(r.trace_refill())
+        auto, passes = r.read_accum()
+        assert passes == 4 * spp
+        assert seen[0][0] == hip.REFILL_UNDECIDED and seen[0][1] < 0.0   # call 0 measured the binning
+        assert seen[1][0] == hip.REFILL_UNDECIDED and seen[1][1] > 0.0 and seen[1][2] < 0.0
+        state, off, on, mask = seen[2]
+        assert state in (hip.REFILL_OFF, hip.REFILL_ON) and off > 0.0 and on > 0.0
+        assert (mask != 0) == (state == hip.REFILL_ON)
+        assert seen[3] == seen[2]
+        r.upload_scene(hyperion.desc)   # a new scene is measured anew
+        assert r.trace_refill()[0] == hip.REFILL_UNDECIDED
+    finally:
+        r.close()
+    fused = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_FUSED)
+    try:
+        fused.upload_scene(hyperion.desc)
+        fused.upload_seeds(host.seed_schedule(0, 4 * spp, fused.tile_count))
+        fused.clear()
+        fused.render(hyperion.camera(w, h), 0, 4 * spp)
+        want, _ = fused.read_accum()
+    finally:
+        fused.close()
+    assert same(auto, want)
+
+
 def test_trip_counts_and_kernel_times(hyperion):
     w, h, md, tile, spp = 640, 360, 7, (64, 36), 4
     r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_TIME_KERNELS)
