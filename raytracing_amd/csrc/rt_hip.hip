@@ -1671,6 +1671,9 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
                 (uint32_t) std::min<size_t>(accel.instances.size(), spare / 2u / 64u);
             d.cached_nodes = (uint32_t) std::min<size_t>(accel.nodes.size(),
                 (spare - d.cached_instances * 64u) / sizeof(wide_node));
+            if (!kTraceCopies) {
+                d.cached_nodes = d.cached_instances = 0u;
+            }
         }
         if (s.tlas_count > 0) {
             // the root of the uploaded TLAS bounds every instance (bvh_linear_node, bvh.h:30-37)

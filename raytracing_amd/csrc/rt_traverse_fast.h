@@ -38,6 +38,11 @@ namespace rtd {
 // there is no overflow path (a private overflow array would live in scratch
 // memory, and scratch-heavy kernels get fewer resident waves).
 constexpr uint32_t kFastLdsEntries = 40;
+// 0: experiments - the trace kernel keeps no LDS copies of nodes and instance records
+#ifndef RT_TRACE_COPIES
+#define RT_TRACE_COPIES 1
+#endif
+constexpr bool kTraceCopies = RT_TRACE_COPIES != 0;
 constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
 
 struct fast_stack {
@@ -48,6 +53,23 @@ struct fast_stack {
     uint32_t cached_nodes;
     uint32_t cached_instances;
 };
+
+// A pointer into the workgroup's LDS, typed as such: through a plain pointer the compiler
+// reads with flat loads (and merges an "LDS or memory" choice into one flat load of a selected
+// address), which are slower than either kind.
+typedef float native_f4 __attribute__((ext_vector_type(4)));
+struct lds_quads {
+    const __attribute__((address_space(3))) native_f4* at;
+    RT_DEV float4 operator[](uint32_t i) const {
+        native_f4 const v = at[i];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    RT_DEV lds_quads operator+(uint32_t quads) const { return lds_quads{at + quads}; }
+};
+RT_DEV lds_quads lds_view(const float4* p) {
+    // the low half of a generic pointer into LDS is the LDS address
+    return lds_quads{(const __attribute__((address_space(3))) native_f4*) (uintptr_t) (uint32_t) (uintptr_t) p};
+}
 
 struct slab_ray {
     f3 inv;   // 1 / direction
@@ -151,8 +173,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         for (;;) {
             if (cur >= 0) {
                 float4 lx, ly, lz, hx, hy, hz, kids;
-                if (CACHED && (uint32_t) cur < stk.cached_nodes) {
-                    const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+                if (kTraceCopies && CACHED && (uint32_t) cur < stk.cached_nodes) {
+                    lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
                     lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
                 } else {
                     const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
@@ -208,8 +230,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
                 const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
                 float4 r0, r1, r2, r3;
-                if (CACHED && rec_index < stk.cached_instances) {
-                    const float4* lp = stk.instance_cache + 4u * rec_index;
+                if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
+                    lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
                     r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
                 } else {
                     r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
@@ -296,8 +318,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     // One inner node: goes to the nearest hit child (pushing the others) or pops.
     auto node_step = [&]() {
         float4 lx, ly, lz, hx, hy, hz, kids;
-        if (CACHED && (uint32_t) cur < stk.cached_nodes) {
-            const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+        if (kTraceCopies && CACHED && (uint32_t) cur < stk.cached_nodes) {
+            lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
             lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
             if (COUNT) {
                 ++cnt.lds_nodes;
@@ -371,8 +393,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
             const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
             float4 r0, r1, r2, r3;
-            if (CACHED && rec_index < stk.cached_instances) {
-                const float4* lp = stk.instance_cache + 4u * rec_index;
+            if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
+                lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
                 r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
                 if (COUNT) {
                     ++cnt.lds_instances;
@@ -493,8 +515,8 @@ struct fast_walk {
 
     RT_DEV void node_step(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         float4 lx, ly, lz, hx, hy, hz, kids;
-        if ((uint32_t) cur < stk.cached_nodes) {
-            const float4* lp = stk.node_cache + kWideNodeQuads * (uint32_t) cur;
+        if (kTraceCopies && (uint32_t) cur < stk.cached_nodes) {
+            lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
             lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
             if (COUNT) {
                 ++cnt.lds_nodes;
@@ -562,8 +584,8 @@ struct fast_walk {
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
             const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
             float4 r0, r1, r2, r3;
-            if (rec_index < stk.cached_instances) {
-                const float4* lp = stk.instance_cache + 4u * rec_index;
+            if (kTraceCopies && rec_index < stk.cached_instances) {
+                lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
                 r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
                 if (COUNT) {
                     ++cnt.lds_instances;

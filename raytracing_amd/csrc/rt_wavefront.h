@@ -804,6 +804,10 @@ constexpr uint32_t kShadeThreads = 256;
 #define RT_SHADE_GROUPS_PER_CU RT_SHADE_WAVES_PER_SIMD
 #endif
 constexpr uint32_t kShadeGroupsPerCu = RT_SHADE_GROUPS_PER_CU;
+// 0: experiments - leave the scene's small tables in memory (1.5-3 % slower on the test scenes)
+#ifndef RT_SHADE_STAGE
+#define RT_SHADE_STAGE 1
+#endif
 // A wave regroups the paths of this many chunks at a time by what shading them costs (see the
 // kernel); its two lists and the results take 8 bytes of LDS per slot.
 #ifndef RT_SHADE_SPAN_CHUNKS
@@ -825,7 +829,7 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
         return;  // none of this workgroup's waves has a chunk
     }
     scene_dev sc = p.sc;
-    {
+    if (RT_SHADE_STAGE) {
         shade_plan const plan = plan_shade_tables(p.sc, kShadeLdsBudget);
         const void* const source[kTableCount] = {p.sc.lights, p.sc.materials, p.sc.meshes,
             p.sc.textures, p.sc.instances, p.sc.transforms};
