@@ -385,6 +385,20 @@ def main():
                             "triangle_tests": tris_l / max(rays_l, 1),
                             "instance_records": work["instance_records"] / max(rays_l, 1),
                             "bytes": bytes_call / max(rays_l, 1)},
+                "lanes_in_use": {
+                    "node_steps": ((work["nodes"] - work["finish_nodes"])
+                                   / (64.0 * work["node_wave_steps"])
+                                   if work.get("node_wave_steps") else None),
+                    "triangle_tests": ((work["tris"] - work["finish_tris"])
+                                       / (64.0 * work["triangle_wave_steps"])
+                                       if work.get("triangle_wave_steps") else None),
+                    "instance_entries": (work["instance_records"]
+                                         / (64.0 * work["instance_wave_steps"])
+                                         if work.get("instance_wave_steps") else None),
+                    "wave_steps_per_ray": {
+                        "node": work.get("node_wave_steps", 0) * 64.0 / max(rays_l, 1),
+                        "triangle": work.get("triangle_wave_steps", 0) * 64.0 / max(rays_l, 1),
+                        "instance": work.get("instance_wave_steps", 0) * 64.0 / max(rays_l, 1)}},
                 "rays_per_launch": rays_l / launches_per_call,
                 "deepest_traversal_stack": cst["max_stack"],
                 "node_fetches_served_from_lds": lds_share,

@@ -290,6 +290,10 @@ typedef struct rt_hip_trace_work_counts {
     uint64_t instance_records, instance_records_from_lds;
     uint64_t finish_nodes, finish_tris;
     uint64_t node_bytes, node_bytes_cached, triangle_bytes, instance_bytes;
+    /* trace launches: how often a wave executed a node step / a triangle test / an instance
+     * entry for any of its lanes; (nodes - finish_nodes) / (64 * node_wave_steps) is the share
+     * of lanes in use in the node steps, and so on */
+    uint64_t node_wave_steps, triangle_wave_steps, instance_wave_steps;
 } rt_hip_trace_work_counts;
 int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out);
 

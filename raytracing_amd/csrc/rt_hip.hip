@@ -2139,6 +2139,9 @@ int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out) {
             out->instance_records_from_lds += s[kStatLdsInstances];
             out->finish_nodes += s[kStatFinishNodes];
             out->finish_tris += s[kStatFinishTris];
+            out->node_wave_steps += s[kStatNodeWaveSteps];
+            out->triangle_wave_steps += s[kStatTriWaveSteps];
+            out->instance_wave_steps += s[kStatInstanceWaveSteps];
         }
         out->node_bytes_cached = (uint64_t) r->sc.cached_nodes * sizeof(wide_node);
         out->node_bytes = r->accel_node_bytes;

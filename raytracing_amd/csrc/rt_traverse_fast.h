@@ -43,6 +43,24 @@ constexpr uint32_t kFastLdsEntries = 40;
 #define RT_TRACE_COPIES 1
 #endif
 constexpr bool kTraceCopies = RT_TRACE_COPIES != 0;
+// The descent loop of the trace launches ends early once fewer lanes than this are still
+// descending: the lanes that hold a leaf stop waiting for the last few.
+#ifndef RT_DESCENT_MIN
+#define RT_DESCENT_MIN 16
+#endif
+constexpr uint32_t kDescentMin = RT_DESCENT_MIN;
+// Likewise the triangle loop of a leaf: once fewer lanes than this still have triangles to
+// test, the rest of their leaves waits for the next round (the leaf code in `cur` is advanced
+// triangle by triangle).
+#ifndef RT_LEAF_MIN
+#define RT_LEAF_MIN 8
+#endif
+constexpr uint32_t kLeafMin = RT_LEAF_MIN;
+// 1: experiments - every step the wave executes the kind of step most of its lanes wait for
+#ifndef RT_TRACE_SCHEDULE
+#define RT_TRACE_SCHEDULE 0
+#endif
+constexpr bool kTraceSchedule = RT_TRACE_SCHEDULE != 0;
 constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
 
 struct fast_stack {
@@ -69,6 +87,13 @@ struct lds_quads {
 RT_DEV lds_quads lds_view(const float4* p) {
     // the low half of a generic pointer into LDS is the LDS address
     return lds_quads{(const __attribute__((address_space(3))) native_f4*) (uintptr_t) (uint32_t) (uintptr_t) p};
+}
+
+// 1 on the first of the lanes executing this line, 0 on the others.
+RT_DEV uint32_t first_active_lane() {
+    unsigned long long const exec = __ballot(1);
+    return (uint32_t) __builtin_amdgcn_mbcnt_hi((uint32_t) (exec >> 32),
+               __builtin_amdgcn_mbcnt_lo((uint32_t) exec, 0u)) == 0u ? 1u : 0u;
 }
 
 struct slab_ray {
@@ -330,6 +355,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         }
         if (COUNT) {
             ++cnt.nodes;
+            cnt.node_wave_steps += first_active_lane();
         }
         int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y), __float_as_int(kids.z),
             __float_as_int(kids.w)};
@@ -376,6 +402,86 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         }
     };
 
+    if constexpr (kTraceSchedule) {
+        for (;;) {
+            bool const want_node = cur >= 0;
+            bool const want_leaf = cur < 0 && in_blas;
+            uint32_t const n_node = (uint32_t) __builtin_popcountll(__ballot(want_node));
+            uint32_t const n_leaf = (uint32_t) __builtin_popcountll(__ballot(want_leaf));
+            uint32_t const n_inst = (uint32_t) __builtin_popcountll(__ballot(1)) - n_node - n_leaf;
+            if (n_node >= n_leaf && n_node >= n_inst) {
+                if (want_node) {
+                    node_step();
+                }
+            } else if (n_leaf >= n_inst) {
+                if (want_leaf) {
+                    uint32_t const code = (uint32_t) ~cur;
+                    uint32_t const first = code >> 3;
+                    uint32_t const left = code & 7u;
+                    const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first]);
+                    float4 const va = tp[0], vb = tp[1], vc = tp[2];
+                    if (COUNT) {
+                        ++cnt.tris;
+                        cnt.tri_wave_steps += first_active_lane();
+                    }
+                    float b0, b1, b2, th;
+                    if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
+                            mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th,
+                            sc.wide_lists_degenerate != 0u)) {
+                        if (ANY) {
+                            return true;
+                        }
+                        t_max = th;
+                        found = true;
+                        best.instance = current_instance;
+                        best.triangle = (uint32_t) __float_as_int(va.w);
+                        best.b0 = b0;
+                        best.b1 = b1;
+                        best.b2 = b2;
+                        best.t = th;
+                    }
+                    if (left != 0u) {
+                        cur = (int32_t) ~(((first + 1u) << 3) | (left - 1u));
+                    } else {
+                        next_subtree();
+                    }
+                }
+            } else if (!want_node && !want_leaf) {
+                uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
+                const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+                float4 r0, r1, r2, r3;
+                if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
+                    lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
+                    r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
+                    if (COUNT) {
+                        ++cnt.lds_instances;
+                    }
+                } else {
+                    r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
+                }
+                if (COUNT) {
+                    ++cnt.instances;
+                    cnt.instance_wave_steps += first_active_lane();
+                }
+                f3 o, d;
+                o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
+                o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
+                o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
+                d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
+                d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
+                d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
+                slab = make_slab_ray(o, d);
+                tr = make_tri_ray(o, d);
+                current_instance = (uint32_t) __float_as_int(r3.y);
+                push(kInstanceMarker);
+                in_blas = true;
+                cur = __float_as_int(r3.x);
+            }
+            if (cur == kDone) {
+                return found;
+            }
+        }
+    }
     for (;;) {
         if (cur >= 0) {
             // The pipeline's trace kernel lets every lane descend until it holds a leaf or has
@@ -383,10 +489,14 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             // wait for the other kinds of step once per round, not on every step.
             do {
                 node_step();
-            } while (cur >= 0);
+            } while (cur >= 0 && (kDescentMin == 0u ||
+                                     (uint32_t) __builtin_popcountll(__ballot(cur >= 0)) >= kDescentMin));
         }
         if (cur == kDone) {
             return found;
+        }
+        if (kDescentMin != 0u && cur >= 0) {
+            continue;  // still descending: the other lanes' leaves came first
         }
         if (!in_blas) {
             // TLAS leaf: exactly one instance.  Enter its BLAS.
@@ -404,6 +514,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             }
             if (COUNT) {
                 ++cnt.instances;
+                cnt.instance_wave_steps += first_active_lane();
             }
             // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
             f3 o, d;
@@ -425,11 +536,13 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         uint32_t const code = (uint32_t) ~cur;
         uint32_t const first = code >> 3;
         uint32_t const count = (code & 7u) + 1u;
-        for (uint32_t k = 0; k < count; ++k) {
+        uint32_t k = 0;
+        do {
             const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
             float4 const va = tp[0], vb = tp[1], vc = tp[2];
             if (COUNT) {
                 ++cnt.tris;
+                cnt.tri_wave_steps += first_active_lane();
             }
             float b0, b1, b2, th;
             if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z), mk3(vc.x, vc.y, vc.z),
@@ -446,8 +559,14 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 best.b2 = b2;
                 best.t = th;
             }
+            ++k;
+        } while (k < count && (kLeafMin == 0u ||
+                                  (uint32_t) __builtin_popcountll(__ballot(k < count)) >= kLeafMin));
+        if (k < count) {
+            cur = (int32_t) ~(((first + k) << 3) | (count - k - 1u));  // the rest of the leaf
+        } else {
+            next_subtree();
         }
-        next_subtree();
     }
 }
 
@@ -527,6 +646,7 @@ struct fast_walk {
         }
         if (COUNT) {
             ++cnt.nodes;
+            cnt.node_wave_steps += first_active_lane();
         }
         int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y), __float_as_int(kids.z),
             __float_as_int(kids.w)};
@@ -576,9 +696,16 @@ struct fast_walk {
     RT_DEV bool round(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         while (cur >= 0) {
             node_step(sc, stk, cnt);
+            if (kDescentMin != 0u &&
+                (uint32_t) __builtin_popcountll(__ballot(cur >= 0)) < kDescentMin) {
+                break;
+            }
         }
         if (cur == kDone) {
             return true;
+        }
+        if (kDescentMin != 0u && cur >= 0) {
+            return false;  // still descending: the other lanes' leaves come first
         }
         if (!in_blas) {
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
@@ -595,6 +722,7 @@ struct fast_walk {
             }
             if (COUNT) {
                 ++cnt.instances;
+                cnt.instance_wave_steps += first_active_lane();
             }
             f3 o, d;
             o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
@@ -614,11 +742,13 @@ struct fast_walk {
         uint32_t const code = (uint32_t) ~cur;
         uint32_t const first = code >> 3;
         uint32_t const count = (code & 7u) + 1u;
-        for (uint32_t k = 0; k < count; ++k) {
+        uint32_t k = 0;
+        do {
             const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
             float4 const va = tp[0], vb = tp[1], vc = tp[2];
             if (COUNT) {
                 ++cnt.tris;
+                cnt.tri_wave_steps += first_active_lane();
             }
             float b0, b1, b2, th;
             if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z), mk3(vc.x, vc.y, vc.z),
@@ -635,8 +765,14 @@ struct fast_walk {
                 best.b2 = b2;
                 best.t = th;
             }
+            ++k;
+        } while (k < count && (kLeafMin == 0u ||
+                                  (uint32_t) __builtin_popcountll(__ballot(k < count)) >= kLeafMin));
+        if (k < count) {
+            cur = (int32_t) ~(((first + k) << 3) | (count - k - 1u));  // the rest of the leaf
+        } else {
+            next_subtree(stk);
         }
-        next_subtree(stk);
         return false;
     }
 };

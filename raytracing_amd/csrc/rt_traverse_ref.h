@@ -31,6 +31,11 @@ struct trace_counters {
     uint32_t lds_nodes = 0;      // of `nodes`: read from the workgroup's LDS copy
     uint32_t instances = 0;      // instance records fetched (TLAS leaves entered)
     uint32_t lds_instances = 0;  // of `instances`: read from LDS
+    // trace launches only: how often a WAVE executed each kind of step (counted by the first
+    // lane taking part), so that steps / (64 x wave steps) is the share of lanes in use
+    uint32_t node_wave_steps = 0;
+    uint32_t tri_wave_steps = 0;
+    uint32_t instance_wave_steps = 0;
 };
 
 constexpr uint32_t kRefStackCapacity = 160;

@@ -62,6 +62,9 @@ enum : uint32_t {
     kStatLdsInstances = 10,  // of those: read from LDS by the trace launches
     kStatFinishNodes = 11,   // of kStatNodes / kStatTris: the finishing kernel's share
     kStatFinishTris = 12,
+    kStatNodeWaveSteps = 13,      // trace launches: executions of each kind of step by a wave
+    kStatTriWaveSteps = 14,
+    kStatInstanceWaveSteps = 15,
     kStatWords = 16,
 };
 constexpr uint32_t kScanThreads = 1024;
@@ -774,12 +777,18 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         unsigned long long const lds_nodes = wave_sum(cnt.lds_nodes);
         unsigned long long const instances = wave_sum(cnt.instances);
         unsigned long long const lds_instances = wave_sum(cnt.lds_instances);
+        unsigned long long const node_wave_steps = wave_sum(cnt.node_wave_steps);
+        unsigned long long const tri_wave_steps = wave_sum(cnt.tri_wave_steps);
+        unsigned long long const instance_wave_steps = wave_sum(cnt.instance_wave_steps);
         if (wave_lane() == 0) {
             add_wave_stat(p, kStatNodes, nodes);
             add_wave_stat(p, kStatTris, tris);
             add_wave_stat(p, kStatLdsNodes, lds_nodes);
             add_wave_stat(p, kStatInstances, instances);
             add_wave_stat(p, kStatLdsInstances, lds_instances);
+            add_wave_stat(p, kStatNodeWaveSteps, node_wave_steps);
+            add_wave_stat(p, kStatTriWaveSteps, tri_wave_steps);
+            add_wave_stat(p, kStatInstanceWaveSteps, instance_wave_steps);
             unsigned long long* const slot =
                 p.wave_stats + (size_t) wave_index() * kStatWords + kStatMaxStack;
             *slot = max(*slot, (unsigned long long) deepest);

@@ -49,7 +49,7 @@ class TraceWork(C.Structure):
     _fields_ = [(name, C.c_uint64) for name in (
         "nodes", "tris", "nodes_from_lds", "instance_records", "instance_records_from_lds",
         "finish_nodes", "finish_tris", "node_bytes", "node_bytes_cached", "triangle_bytes",
-        "instance_bytes")]
+        "instance_bytes", "node_wave_steps", "triangle_wave_steps", "instance_wave_steps")]
 
 
 PROBE_RAND01, PROBE_HASH_COMBINE, PROBE_RAND_UINT, PROBE_HIT_AABB, PROBE_HIT_TRIANGLE, \
