@@ -56,6 +56,16 @@ constexpr uint32_t kDescentMin = RT_DESCENT_MIN;
 #define RT_LEAF_MIN 8
 #endif
 constexpr uint32_t kLeafMin = RT_LEAF_MIN;
+// The refilling trace loop also holds back instance entries and leaves until this many lanes
+// wait for them (unless nothing else can run).
+#ifndef RT_INSTANCE_MIN
+#define RT_INSTANCE_MIN 16
+#endif
+constexpr uint32_t kInstanceMin = RT_INSTANCE_MIN;
+#ifndef RT_LEAF_START
+#define RT_LEAF_START 16
+#endif
+constexpr uint32_t kLeafStart = RT_LEAF_START;
 // 1: experiments - every step the wave executes the kind of step most of its lanes wait for
 #ifndef RT_TRACE_SCHEDULE
 #define RT_TRACE_SCHEDULE 0
@@ -692,57 +702,46 @@ struct fast_walk {
         }
     }
 
-    // Returns true when the walk is over.
-    RT_DEV bool round(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
-        while (cur >= 0) {
-            node_step(sc, stk, cnt);
-            if (kDescentMin != 0u &&
-                (uint32_t) __builtin_popcountll(__ballot(cur >= 0)) < kDescentMin) {
-                break;
-            }
-        }
-        if (cur == kDone) {
-            return true;
-        }
-        if (kDescentMin != 0u && cur >= 0) {
-            return false;  // still descending: the other lanes' leaves come first
-        }
-        if (!in_blas) {
-            uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-            const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
-            float4 r0, r1, r2, r3;
-            if (kTraceCopies && rec_index < stk.cached_instances) {
-                lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
-                r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
-                if (COUNT) {
-                    ++cnt.lds_instances;
-                }
-            } else {
-                r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
-            }
+    RT_DEV void enter_instance(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
+        uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
+        const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+        float4 r0, r1, r2, r3;
+        if (kTraceCopies && rec_index < stk.cached_instances) {
+            lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
+            r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
             if (COUNT) {
-                ++cnt.instances;
-                cnt.instance_wave_steps += first_active_lane();
+                ++cnt.lds_instances;
             }
-            f3 o, d;
-            o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
-            o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
-            o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
-            d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
-            d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
-            d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
-            slab = make_slab_ray(o, d);
-            tr = make_tri_ray(o, d);
-            current_instance = (uint32_t) __float_as_int(r3.y);
-            push(stk, cnt, kInstanceMarker);
-            in_blas = true;
-            cur = __float_as_int(r3.x);
-            return false;
+        } else {
+            r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
         }
+        if (COUNT) {
+            ++cnt.instances;
+            cnt.instance_wave_steps += first_active_lane();
+        }
+        f3 o, d;
+        o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
+        o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
+        o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
+        d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
+        d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
+        d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
+        slab = make_slab_ray(o, d);
+        tr = make_tri_ray(o, d);
+        current_instance = (uint32_t) __float_as_int(r3.y);
+        push(stk, cnt, kInstanceMarker);
+        in_blas = true;
+        cur = __float_as_int(r3.x);
+    }
+
+    // Tests triangles of the leaf in `cur` until the leaf is done or fewer than kLeafMin lanes
+    // still have some left; an occlusion walk that finds a hit is over (cur = kDone).
+    RT_DEV void test_leaf(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         uint32_t const code = (uint32_t) ~cur;
         uint32_t const first = code >> 3;
         uint32_t const count = (code & 7u) + 1u;
         uint32_t k = 0;
+        bool stop = false;
         do {
             const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
             float4 const va = tp[0], vb = tp[1], vc = tp[2];
@@ -755,25 +754,71 @@ struct fast_walk {
                     tr, t_max, b0, b1, b2, th, sc.wide_lists_degenerate != 0u)) {
                 found = true;
                 if (ANY) {
-                    return true;
+                    stop = true;
+                } else {
+                    t_max = th;
+                    best.instance = current_instance;
+                    best.triangle = (uint32_t) __float_as_int(va.w);
+                    best.b0 = b0;
+                    best.b1 = b1;
+                    best.b2 = b2;
+                    best.t = th;
                 }
-                t_max = th;
-                best.instance = current_instance;
-                best.triangle = (uint32_t) __float_as_int(va.w);
-                best.b0 = b0;
-                best.b1 = b1;
-                best.b2 = b2;
-                best.t = th;
             }
             ++k;
-        } while (k < count && (kLeafMin == 0u ||
-                                  (uint32_t) __builtin_popcountll(__ballot(k < count)) >= kLeafMin));
-        if (k < count) {
+        } while (!stop && k < count &&
+                 (kLeafMin == 0u ||
+                     (uint32_t) __builtin_popcountll(__ballot(k < count)) >= kLeafMin));
+        if (stop) {
+            cur = kDone;
+        } else if (k < count) {
             cur = (int32_t) ~(((first + k) << 3) | (count - k - 1u));  // the rest of the leaf
         } else {
             next_subtree(stk);
         }
-        return false;
+    }
+
+    // One round; returns true when the walk is over.  A kind of step runs when enough of the
+    // wave's lanes wait for it (node steps: kDescentMin, instance entries: kInstanceMin,
+    // triangles: kLeafStart); when no kind has enough, the one most lanes wait for runs.
+    // Must be called by every lane of the wave that has a walk, together.
+    RT_DEV bool round(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
+        auto lanes = [](bool v) { return (uint32_t) __builtin_popcountll(__ballot(v)); };
+        auto descend = [&]() {
+            while (cur >= 0) {
+                node_step(sc, stk, cnt);
+                if (kDescentMin != 0u && lanes(cur >= 0) < kDescentMin) {
+                    break;
+                }
+            }
+        };
+        uint32_t const n_node = lanes(cur >= 0);
+        bool const ran = n_node >= max(kDescentMin, 1u);
+        if (ran) {
+            descend();
+        }
+        bool const at_instance = cur < 0 && cur != kDone && !in_blas;
+        bool const at_leaf = cur < 0 && cur != kDone && in_blas;
+        uint32_t const n_instance = lanes(at_instance);
+        uint32_t const n_leaf = lanes(at_leaf);
+        bool run_instance = n_instance >= max(kInstanceMin, 1u);
+        bool run_leaf = n_leaf >= max(kLeafStart, 1u);
+        if (!ran && !run_instance && !run_leaf) {
+            if (n_node >= n_instance && n_node >= n_leaf) {
+                descend();
+            } else if (n_instance >= n_leaf) {
+                run_instance = true;
+            } else {
+                run_leaf = true;
+            }
+        }
+        if (run_instance && at_instance) {
+            enter_instance(sc, stk, cnt);
+        }
+        if (run_leaf && at_leaf) {
+            test_leaf(sc, stk, cnt);
+        }
+        return cur == kDone;
     }
 };
 
