@@ -196,14 +196,24 @@ def committed_counters(args):
     return None
 
 
-def count_work(hip, host, sc, cam, args, tile, accel, device_index, first_pass, seeds_row):
+def count_work(hip, host, sc, cam, args, tile, accel, device_index, first_pass, seeds_row,
+               refill):
     """One untimed render call of the same step with the node / triangle counters on: what the
-    trace launches of this build fetch per ray, and how much of it their LDS copy serves."""
+    trace launches of this build fetch per ray, how much of it their LDS copy serves and how many
+    lanes their steps keep in use (`refill`: hand out rays the way the timed steps did)."""
     flags = hip.FLAG_COUNT_NODES | hip.FLAG_NO_BIN_RAYS  # the order of the queues changes no count
     r = hip.HipRenderer(args.width, args.height, args.max_depth, tile, device=device_index,
                         accel=accel, flags=flags)
     try:
-        r.upload_scene(sc.desc)
+        before = os.environ.get("RT_HIP_TRACE_REFILL")
+        os.environ["RT_HIP_TRACE_REFILL"] = "1" if refill else "0"   # read at upload
+        try:
+            r.upload_scene(sc.desc)
+        finally:
+            if before is None:
+                del os.environ["RT_HIP_TRACE_REFILL"]
+            else:
+                os.environ["RT_HIP_TRACE_REFILL"] = before
         r.upload_seeds(seeds_row, first_pass)
         r.clear()
         r.render(cam, first_pass, args.spp_per_step)
@@ -336,7 +346,8 @@ def main():
                          "shade_ms_per_call": shade_ms * shade_n / launches}
             # the same step once more, untimed, with the work counters on
             cst, work, per_bounce = count_work(
-                hip, host, sc, cam, args, tile, accel, local_rank, first_pass, seeds[:spp])
+                hip, host, sc, cam, args, tile, accel, local_rank, first_pass, seeds[:spp],
+                refill[0] != hip.REFILL_OFF)
             if args.pipeline == "fused":
                 rays_l = cst["closest_rays"] + cst["shadow_rays"]
                 closest_l, shadow_l = cst["closest_rays"], cst["shadow_rays"]

@@ -56,10 +56,13 @@ enum {
     RT_HIP_FLAG_TIME_KERNELS = 4u,
     /* Ray binning in the pipeline: before each bounce's trace launch, regroup the ray queues
      * so that a wave traces rays that start in the same part of the scene and point the same
-     * way.  Pays off on scenes whose incoherent rays are expensive to trace (interiors), costs
-     * a few percent on scenes whose rays are cheap; images are bit-identical either way.
-     * Default (neither flag): decided per uploaded scene and per bounce from the measured
-     * cost of tracing that bounce's rays in the first large render call, see
+     * way.  It pays only where the trace launch works through its queue in fixed chunks of 64
+     * rays and those rays are expensive and unlike each other; a trace launch that refills its
+     * finished lanes (rt_hip_trace_refill) gains nothing from it.  Images are bit-identical
+     * either way.  Default (neither flag): decided per uploaded scene and per bounce from the
+     * first two large render calls - the first runs with fixed chunks and unbinned queues and
+     * is timed bounce by bounce, the second refills; a bounce is binned when fixed chunks won
+     * it and its rays cost enough, see
      * rt_hip_ray_binning.  The flags force it on (every bounce) or off. */
     RT_HIP_FLAG_BIN_RAYS = 8u,
     RT_HIP_FLAG_NO_BIN_RAYS = 16u,
@@ -298,17 +301,18 @@ typedef struct rt_hip_trace_work_counts {
 int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out);
 
 /* Diagnostics of the pipeline: whether ray binning is in use for the uploaded scene
- * (RT_HIP_BINNING_*: ON = for at least one bounce) and, when it was decided by measurement,
- * the measured cost of tracing one ray of the third bounce without binning, in nanoseconds
- * of whole-GPU time (0 when forced by a flag or not yet measured).  No counterpart in the
+ * (RT_HIP_BINNING_*: ON = for at least one bounce; UNDECIDED until the second large render
+ * call has been measured) and, when it was decided by measurement, the measured cost of
+ * tracing one ray of the third bounce in fixed chunks without binning, in nanoseconds of
+ * whole-GPU time (0 when forced by a flag or not yet measured).  No counterpart in the
  * reference. */
 int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per_ray);
 
 /* Diagnostics of the pipeline: how its trace launches hand out rays on the uploaded scene
  * (RT_HIP_REFILL_*).  A wave either takes fixed chunks of 64 rays or gives each lane that has
  * finished its ray the next one (once half its lanes wait); which is faster depends on how
- * unequal the rays' walks are, so after the ray binning is settled one large render call is
- * timed in each mode and the faster kept, bounce by bounce (ON = some bounce refills).  ms_off /
+ * unequal the rays' walks are, so the first two large render calls of a scene are timed, one
+ * each way, and the faster is kept bounce by bounce (ON = some bounce refills).  ms_off /
  * ms_on: the summed trace launches of those two calls, -1 until measured.  trip_mask: bit b set
  * = the trace launch of bounce b refills (bit 31 stands for every later bounce).  Out pointers
  * other than `state` may be null.  Images are bit-identical either way.  No counterpart in the

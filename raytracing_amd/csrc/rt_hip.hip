@@ -429,6 +429,7 @@ struct rt_hip_renderer {
     std::vector<float> refill_trip_ms[2];  // the same per trip
     std::vector<uint8_t> refill_trip;      // the verdict per trip (trips beyond it: the last one's)
     uint32_t probe_kind = 0;           // what the probe in flight measures: 1 binning, 2 / 3 refill off / on
+    bool bin_candidates = false;       // bin_trip holds the bounces whose rays are dear enough
     bool probe_pending = false;
     uint32_t probe_trips = 0;          // trips timed by the probe in flight
     std::vector<hipEvent_t> probe_events;  // 2 per trip (start, stop), created on demand
@@ -755,6 +756,26 @@ constexpr uint32_t kBinningMinRays = 8u << 20;  // per trip
 constexpr uint32_t kProbeTrip = 2;              // the trip whose cost rt_hip_ray_binning reports
 constexpr uint32_t kProbeMinPaths = 4u << 20;   // smaller batches time the launches, not the rays
 
+// The binning verdict, once the way the trace launches hand out rays is known: a bounce whose
+// trace launch refills its lanes is not binned.  Refilling takes the cost of unequal rays out
+// of the wave, which is what the regrouped queues were for, and leaves the regrouping's own
+// launches as pure cost (measured with both on: staircase 309 against 342 Msamples/s without
+// the binning, mustang 1551 against 1656, the 10 000-instance scene 835 against 865).
+void settle_binning(rt_hip_renderer& r) {
+    bool any = false;
+    for (size_t trip = 0; trip < r.bin_trip.size(); ++trip) {
+        bool refills = r.refill == RT_HIP_REFILL_ON;
+        if (refills && !r.refill_trip.empty()) {
+            refills = r.refill_trip[std::min(trip, r.refill_trip.size() - 1)] != 0;
+        }
+        if (refills) {
+            r.bin_trip[trip] = 0;
+        }
+        any = any || r.bin_trip[trip] != 0;
+    }
+    r.binning = any ? RT_HIP_BINNING_ON : RT_HIP_BINNING_OFF;
+}
+
 // Settles an outstanding probe if its events have completed (never waits).
 void settle_binning_probe(rt_hip_renderer& r) {
     if (!r.probe_pending || hipEventQuery(r.probe_done) != hipSuccess) {
@@ -782,14 +803,30 @@ void settle_binning_probe(rt_hip_renderer& r) {
                 any = any || r.refill_trip[trip] != 0;
             }
             r.refill = any ? RT_HIP_REFILL_ON : RT_HIP_REFILL_OFF;
+            if (r.binning == RT_HIP_BINNING_UNDECIDED && r.bin_candidates) {
+                settle_binning(r);
+            }
         }
         return;
     }
+    // kind 1: fixed chunks, queues as compacted - the base line of both decisions
+    bool const refill_open = r.refill == RT_HIP_REFILL_UNDECIDED &&
+                             r.cfg.accel == RT_HIP_ACCEL_REBUILT;
     r.bin_trip.assign(r.probe_trips, 0);
-    bool any = false;
-    for (uint32_t trip = 1; trip < r.probe_trips; ++trip) {
+    if (refill_open) {
+        r.refill_trip_ms[0].assign(r.probe_trips, 0.0f);
+        r.refill_ms[0] = 0.0;
+    }
+    for (uint32_t trip = 0; trip < r.probe_trips; ++trip) {
         float ms = 0.0f;
         HIP_CHECK(hipEventElapsedTime(&ms, r.probe_events[2 * trip], r.probe_events[2 * trip + 1]));
+        if (refill_open) {
+            r.refill_trip_ms[0][trip] = ms;
+            r.refill_ms[0] += (double) ms;
+        }
+        if (trip == 0u) {
+            continue;  // camera rays are traced in pixel order
+        }
         const uint32_t* const ctl = r.probe_counts + trip * kCtlWords;
         uint64_t const rays = (uint64_t) ctl[kCtlClosest] + ctl[kCtlShadow];
         double const ns = rays > 0 ? (double) ms * 1e6 / (double) rays : 0.0;
@@ -797,9 +834,11 @@ void settle_binning_probe(rt_hip_renderer& r) {
             r.probe_ns_per_ray = ns;
         }
         r.bin_trip[trip] = rays >= kBinningMinRays && ns > kBinningPaysAboveNs ? 1 : 0;
-        any = any || r.bin_trip[trip] != 0;
     }
-    r.binning = any ? RT_HIP_BINNING_ON : RT_HIP_BINNING_OFF;
+    r.bin_candidates = true;
+    if (!refill_open) {
+        settle_binning(r);
+    }
 }
 
 // Launch geometry of the pipeline's kernels on this renderer's device, their LDS allowances
@@ -939,10 +978,14 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     };
     // measure this call?  (one batch is enough; a probe in flight is left alone)
     bool const large = per_pass * batch >= kProbeMinPaths;
-    bool probe = !fixed && r.binning == RT_HIP_BINNING_UNDECIDED && !r.probe_pending &&
-                 trips > 1u && large;
+    // The first large call runs with fixed chunks and the queues as compacted and is timed bounce
+    // by bounce (kind 1): the base line.  The second refills (kind 3); then both policies are
+    // settled.  (Kind 2: the base line again, when a flag has fixed the binning beforehand.)
+    bool probe = !fixed && r.binning == RT_HIP_BINNING_UNDECIDED && !r.bin_candidates &&
+                 !r.probe_pending && trips > 1u && large;
     uint32_t probe_kind = probe ? 1u : 0u;
-    if (!fixed && !probe && r.binning != RT_HIP_BINNING_UNDECIDED && !r.probe_pending && large &&
+    if (!fixed && !probe && !r.probe_pending && large &&
+        (r.binning != RT_HIP_BINNING_UNDECIDED || r.bin_candidates || trips <= 1u) &&
         r.refill == RT_HIP_REFILL_UNDECIDED && r.cfg.accel == RT_HIP_ACCEL_REBUILT) {
         probe = true;
         probe_kind = r.refill_ms[0] < 0.0 ? 2u : 3u;
@@ -1134,7 +1177,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
             if (each) {
                 t = r.begin_timing(stream, RT_HIP_KERNEL_EXTEND);
             }
-            bool const probe_here = probe && (trip >= 1u || probe_kind != 1u);
+            bool const probe_here = probe;
             if (probe_here) {
                 HIP_CHECK(hipEventRecord(r.probe_events[2 * trip], stream));
             }
@@ -1689,6 +1732,7 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         r->refill = RT_HIP_REFILL_UNDECIDED;
         r->refill_ms[0] = r->refill_ms[1] = -1.0;
         r->refill_trip.clear();
+        r->bin_candidates = false;
         if (char const* const v = getenv("RT_HIP_TRACE_REFILL")) {  // experiments: force it
             r->refill = atoi(v) != 0 ? RT_HIP_REFILL_ON : RT_HIP_REFILL_OFF;
         }
