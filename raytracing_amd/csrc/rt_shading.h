@@ -38,6 +38,17 @@ RT_DEV uint32_t wrap_repeat(int i, uint32_t size) {
     return (uint32_t) m;
 }
 
+// byte / 255.0f, correctly rounded, in three operations instead of the eleven of a general
+// division: the product with the rounded reciprocal is off by at most one unit in the last
+// place and one residual step repairs it - checked against the division for all 256 bytes
+// (tests/test_texture_unorm.py).
+RT_DEV float unorm8(uint8_t byte) {
+    float const x = (float) byte;
+    float const r = 1.0f / 255.0f;
+    float const q = x * r;
+    return __builtin_fmaf(__builtin_fmaf(-q, 255.0f, x), r, q);
+}
+
 RT_DEV f4 load_texel(texture_dev const& t, uint32_t x, uint32_t y) {
     size_t const idx = (size_t) y * t.width + x;
     if (t.format == RT_TEX_F32X4) {
@@ -45,8 +56,7 @@ RT_DEV f4 load_texel(texture_dev const& t, uint32_t x, uint32_t y) {
         return f4{p.x, p.y, p.z, p.w};
     }
     uchar4 const p = reinterpret_cast<const uchar4*>(t.data)[idx];
-    return f4{(float) p.x / 255.0f, (float) p.y / 255.0f, (float) p.z / 255.0f,
-        (float) p.w / 255.0f};
+    return f4{unorm8(p.x), unorm8(p.y), unorm8(p.z), unorm8(p.w)};
 }
 
 RT_DEV f4 sample_texture(scene_dev const& sc, int tex, float u, float v) {
