@@ -193,7 +193,8 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
     // Ray set-up runs for the whole wave at once, outside the divergent loop.
     slab_ray const world_slab = make_slab_ray(origin, direction);
     slab_ray slab = world_slab;
-    tri_ray tr = make_tri_ray(origin, direction);
+    // triangles are tested inside instances only, with the object-space ray set up on entry
+    tri_ray tr{};
     uint32_t current_instance = 0;
     int32_t cur = sc.wide_tlas_root;
     bool in_blas = false;
@@ -605,7 +606,7 @@ struct fast_walk {
         direction = d;
         world_slab = make_slab_ray(o, d);
         slab = world_slab;
-        tr = make_tri_ray(o, d);
+        tr = tri_ray{};  // triangles are tested inside instances only: set up on entry
         t_max = t_limit;
         found = false;
         best.instance = RT_HIP_MISS;
