@@ -214,6 +214,34 @@ def test_trace_refill_is_decided_by_measurement(hyperion):
     assert same(auto, want)
 
 
+@pytest.mark.parametrize("refill", ["0", "1"])
+def test_trace_work_counters(monkeypatch, hyperion, refill):
+    """rt_hip_trace_work: the fetch counts repeat the statistics, and the wave-step counters
+    bound them - a wave step serves between 1 and 64 lanes."""
+    monkeypatch.setenv("RT_HIP_TRACE_REFILL", refill)
+    w, h, md, tile, spp = 640, 360, 7, (64, 36), 4
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_COUNT_NODES)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+        r.clear()
+        r.render(hyperion.camera(w, h), 0, spp)
+        st = r.stats()
+        work = r.trace_work()
+    finally:
+        r.close()
+    assert work["nodes"] == st["nodes_visited"] and work["tris"] == st["tris_tested"]
+    assert work["nodes_from_lds"] <= work["nodes"]
+    assert work["instance_records_from_lds"] <= work["instance_records"]
+    for steps, wave_steps in (
+            (work["nodes"] - work["finish_nodes"], work["node_wave_steps"]),
+            (work["tris"] - work["finish_tris"], work["triangle_wave_steps"])):
+        assert 0 < wave_steps <= steps <= 64 * wave_steps
+    # instance entries of the finishing kernel are not told apart: only the lower bound holds
+    assert 0 < work["instance_wave_steps"] <= work["instance_records"]
+    assert work["node_bytes"] > 0 and work["triangle_bytes"] > 0 and work["instance_bytes"] > 0
+
+
 def test_trip_counts_and_kernel_times(hyperion):
     w, h, md, tile, spp = 640, 360, 7, (64, 36), 4
     r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_TIME_KERNELS)
