@@ -1103,7 +1103,8 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         HIP_CHECK(hipGetLastError());
     };
     // Paths alive below which a batch is handed to the finishing kernel (decided on the
-    // device after every compaction): 1 % of the batch, at least a GPU's worth of lanes.
+    // device after every compaction): 0.4 % of the batch, at least a GPU's worth of lanes
+    // (1 % before the trace launches refilled their lanes: mustang -2 %, 4K scene -1.7 %).
     int const handover_setting = r.handover_setting;
     auto finish = [&](uint32_t trip, uint32_t chunk_bound) {
         dim3 const grid(std::max(1u, std::min(r.wf_finish_grid, chunk_bound)));
@@ -1165,7 +1166,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         HIP_CHECK(hipMemsetAsync(w.control, 0, (size_t) (trips + 1u) * kCtlWords * 4, stream));
         uint32_t const handover_below =
             handover_setting >= 0 ? (uint32_t) handover_setting
-                                  : (uint32_t) std::max<size_t>(paths / 100u, 65536u);
+                                  : (uint32_t) std::max<size_t>(paths / 256u, 65536u);
         for (uint32_t trip = 0; trip < trips; ++trip) {
             if (trip > 0u) {
                 finish(trip, chunk_bound);  // a no-op unless the compaction handed over
