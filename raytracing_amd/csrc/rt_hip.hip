@@ -1698,6 +1698,12 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             if (accel.max_stack_bound > kFastLdsEntries) {
                 throw std::runtime_error("upload_scene: rebuilt BVH exceeds the traversal stack");
             }
+            // the traversal addresses these arrays with 32-bit byte offsets
+            if (accel.nodes.size() * sizeof(wide_node) >= ((size_t) 1 << 32) ||
+                accel.tris.size() * sizeof(tri_pos) >= ((size_t) 1 << 32) ||
+                accel.instances.size() * sizeof(instance_rec) >= ((size_t) 1 << 32)) {
+                throw std::runtime_error("upload_scene: rebuilt BVH exceeds 4 GiB per array");
+            }
             d.wide_nodes = r->upload(accel.nodes.data(), accel.nodes.size());
             d.wide_tris = r->upload(accel.tris.data(), accel.tris.size());
             d.wide_instances = r->upload(accel.instances.data(), accel.instances.size());

@@ -106,6 +106,15 @@ RT_DEV uint32_t first_active_lane() {
                __builtin_amdgcn_mbcnt_lo((uint32_t) exec, 0u)) == 0u ? 1u : 0u;
 }
 
+// Element `index` of a device array whose byte size stays below 4 GiB: the byte offset is
+// formed in 32 bits, so the load takes the uniform base from scalar registers and the offset
+// from one vector register instead of a 64-bit shift and add per lane.
+template <class T>
+RT_DEV const float4* quads_at(const T* base, uint32_t index) {
+    return reinterpret_cast<const float4*>(
+        reinterpret_cast<const char*>(base) + index * (uint32_t) sizeof(T));
+}
+
 struct slab_ray {
     f3 inv;   // 1 / direction
     f3 oinv;  // -origin * inv   (t = plane * inv + oinv)
@@ -213,7 +222,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                     lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
                     lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
                 } else {
-                    const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+                    const float4* np = quads_at(sc.wide_nodes, (uint32_t) cur);
                     lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
                 }
                 if (COUNT) {
@@ -264,7 +273,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
             } else if (!in_blas) {
                 // TLAS leaf: exactly one instance.  Enter its BLAS.
                 uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-                const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+                const float4* ip = quads_at(sc.wide_instances, rec_index);
                 float4 r0, r1, r2, r3;
                 if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
                     lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
@@ -296,7 +305,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 uint32_t const first = code >> 3;
                 uint32_t const count = (code & 7u) + 1u;
                 for (uint32_t k = 0; k < count; ++k) {
-                    const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+                    const float4* tp = quads_at(sc.wide_tris, first + k);
                     float4 const va = tp[0], vb = tp[1], vc = tp[2];
                     if (COUNT) {
                         ++cnt.tris;
@@ -361,7 +370,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 ++cnt.lds_nodes;
             }
         } else {
-            const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+            const float4* np = quads_at(sc.wide_nodes, (uint32_t) cur);
             lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
         }
         if (COUNT) {
@@ -429,7 +438,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                     uint32_t const code = (uint32_t) ~cur;
                     uint32_t const first = code >> 3;
                     uint32_t const left = code & 7u;
-                    const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first]);
+                    const float4* tp = quads_at(sc.wide_tris, first);
                     float4 const va = tp[0], vb = tp[1], vc = tp[2];
                     if (COUNT) {
                         ++cnt.tris;
@@ -459,7 +468,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
                 }
             } else if (!want_node && !want_leaf) {
                 uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-                const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+                const float4* ip = quads_at(sc.wide_instances, rec_index);
                 float4 r0, r1, r2, r3;
                 if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
                     lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
@@ -512,7 +521,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         if (!in_blas) {
             // TLAS leaf: exactly one instance.  Enter its BLAS.
             uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-            const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+            const float4* ip = quads_at(sc.wide_instances, rec_index);
             float4 r0, r1, r2, r3;
             if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
                 lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
@@ -549,7 +558,7 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         uint32_t const count = (code & 7u) + 1u;
         uint32_t k = 0;
         do {
-            const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+            const float4* tp = quads_at(sc.wide_tris, first + k);
             float4 const va = tp[0], vb = tp[1], vc = tp[2];
             if (COUNT) {
                 ++cnt.tris;
@@ -652,7 +661,7 @@ struct fast_walk {
                 ++cnt.lds_nodes;
             }
         } else {
-            const float4* np = reinterpret_cast<const float4*>(&sc.wide_nodes[cur]);
+            const float4* np = quads_at(sc.wide_nodes, (uint32_t) cur);
             lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
         }
         if (COUNT) {
@@ -705,7 +714,7 @@ struct fast_walk {
 
     RT_DEV void enter_instance(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-        const float4* ip = reinterpret_cast<const float4*>(&sc.wide_instances[rec_index]);
+        const float4* ip = quads_at(sc.wide_instances, rec_index);
         float4 r0, r1, r2, r3;
         if (kTraceCopies && rec_index < stk.cached_instances) {
             lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
@@ -744,7 +753,7 @@ struct fast_walk {
         uint32_t k = 0;
         bool stop = false;
         do {
-            const float4* tp = reinterpret_cast<const float4*>(&sc.wide_tris[first + k]);
+            const float4* tp = quads_at(sc.wide_tris, first + k);
             float4 const va = tp[0], vb = tp[1], vc = tp[2];
             if (COUNT) {
                 ++cnt.tris;
