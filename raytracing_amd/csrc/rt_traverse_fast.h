@@ -66,11 +66,6 @@ constexpr uint32_t kInstanceMin = RT_INSTANCE_MIN;
 #define RT_LEAF_START 16
 #endif
 constexpr uint32_t kLeafStart = RT_LEAF_START;
-// 1: experiments - every step the wave executes the kind of step most of its lanes wait for
-#ifndef RT_TRACE_SCHEDULE
-#define RT_TRACE_SCHEDULE 0
-#endif
-constexpr bool kTraceSchedule = RT_TRACE_SCHEDULE != 0;
 constexpr int32_t kInstanceMarker = 0x7FFFFFFF;
 
 struct fast_stack {
@@ -422,86 +417,6 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         }
     };
 
-    if constexpr (kTraceSchedule) {
-        for (;;) {
-            bool const want_node = cur >= 0;
-            bool const want_leaf = cur < 0 && in_blas;
-            uint32_t const n_node = (uint32_t) __builtin_popcountll(__ballot(want_node));
-            uint32_t const n_leaf = (uint32_t) __builtin_popcountll(__ballot(want_leaf));
-            uint32_t const n_inst = (uint32_t) __builtin_popcountll(__ballot(1)) - n_node - n_leaf;
-            if (n_node >= n_leaf && n_node >= n_inst) {
-                if (want_node) {
-                    node_step();
-                }
-            } else if (n_leaf >= n_inst) {
-                if (want_leaf) {
-                    uint32_t const code = (uint32_t) ~cur;
-                    uint32_t const first = code >> 3;
-                    uint32_t const left = code & 7u;
-                    const float4* tp = quads_at(sc.wide_tris, first);
-                    float4 const va = tp[0], vb = tp[1], vc = tp[2];
-                    if (COUNT) {
-                        ++cnt.tris;
-                        cnt.tri_wave_steps += first_active_lane();
-                    }
-                    float b0, b1, b2, th;
-                    if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
-                            mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th,
-                            sc.wide_lists_degenerate != 0u)) {
-                        if (ANY) {
-                            return true;
-                        }
-                        t_max = th;
-                        found = true;
-                        best.instance = current_instance;
-                        best.triangle = (uint32_t) __float_as_int(va.w);
-                        best.b0 = b0;
-                        best.b1 = b1;
-                        best.b2 = b2;
-                        best.t = th;
-                    }
-                    if (left != 0u) {
-                        cur = (int32_t) ~(((first + 1u) << 3) | (left - 1u));
-                    } else {
-                        next_subtree();
-                    }
-                }
-            } else if (!want_node && !want_leaf) {
-                uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-                const float4* ip = quads_at(sc.wide_instances, rec_index);
-                float4 r0, r1, r2, r3;
-                if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
-                    lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
-                    r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
-                    if (COUNT) {
-                        ++cnt.lds_instances;
-                    }
-                } else {
-                    r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
-                }
-                if (COUNT) {
-                    ++cnt.instances;
-                    cnt.instance_wave_steps += first_active_lane();
-                }
-                f3 o, d;
-                o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
-                o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
-                o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
-                d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
-                d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
-                d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
-                slab = make_slab_ray(o, d);
-                tr = make_tri_ray(o, d);
-                current_instance = (uint32_t) __float_as_int(r3.y);
-                push(kInstanceMarker);
-                in_blas = true;
-                cur = __float_as_int(r3.x);
-            }
-            if (cur == kDone) {
-                return found;
-            }
-        }
-    }
     for (;;) {
         if (cur >= 0) {
             // The pipeline's trace kernel lets every lane descend until it holds a leaf or has
@@ -591,10 +506,11 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
 }
 
 // The same walk as trace_fast<.., CACHED = true>, cut into resumable rounds: start() takes a
-// ray, round() runs one round (descend until the lane holds a leaf or has nothing left, then
-// enter the instance or test the leaf's triangles and pop) and says whether the walk is over.
-// A wave that keeps one walk per lane can hand a finished lane its next ray while the other
-// lanes are still walking (wf_extend_kernel).  Same visiting order, same arithmetic.
+// ray, round() runs one round for the wave (see there) and says whether this lane's walk is
+// over.  A wave that keeps one walk per lane can hand a finished lane its next ray while the
+// other lanes are still walking (wf_extend_kernel).  Each ray's own sequence of steps - the
+// visiting order and the arithmetic - is that of trace_fast; only which lanes step together
+// differs, which no result depends on.
 template <bool ANY, bool COUNT>
 struct fast_walk {
     f3 origin, direction;

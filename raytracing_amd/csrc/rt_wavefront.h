@@ -574,10 +574,6 @@ constexpr uint32_t kExtendThreads = 1024;
 #define RT_REFILL_IDLE 32
 #endif
 constexpr uint32_t kRefillIdle = RT_REFILL_IDLE;  // lanes that must wait before a wave refills
-#ifndef RT_REFILL_RUN
-#define RT_REFILL_RUN 1
-#endif
-constexpr uint32_t kRefillRun = RT_REFILL_RUN;    // consecutive chunks a wave takes at a time
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
 
 // FIRST: trip 0 - the rays are the primary rays of pids 0 .. paths-1, built on the spot.
@@ -628,17 +624,15 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         // One walk per lane, refilled: the rays of a wave need very different numbers of steps
         // (the mean over the maximum of 64 is what bounds the lanes in use), so a lane whose
         // ray is done takes the wave's next ray - but only once at least kRefillIdle lanes
-        // wait, so that the per-ray set-up (six exact divisions) runs on many lanes at once.
-        // A wave takes runs of kRefillRun consecutive chunks (run r of wave w starts at chunk
-        // (w + r W) kRefillRun): rays fetched into the same wave come from neighbouring
-        // chunks - the same or adjacent bins when the queue is binned - and runs are dealt
-        // round robin so that every wave gets work from all over the queue.
+        // wait, so that the per-ray set-up (three exact divisions) runs on many lanes at once.
+        // Slot j of wave w is ray (w + (j / 64) W) 64 + j % 64 of the queue: the waves take the
+        // queue's 64-ray chunks round robin, as the fixed-chunk loop below does.
         uint32_t const w = wave_index(), W = wave_total();
         unsigned long long const below = (1ull << wave_lane()) - 1ull;
         auto run = [&](auto walk, uint32_t n, auto fetch, auto deliver) {
-            uint32_t const runs = (n + kRefillRun * 64u - 1u) / (kRefillRun * 64u);
-            uint32_t const my_runs = w < runs ? (runs - w + W - 1u) / W : 0u;
-            uint32_t const mine = my_runs * kRefillRun * 64u;  // slots; those past n have no ray
+            uint32_t const chunks = (n + 63u) / 64u;
+            uint32_t const my_chunks = w < chunks ? (chunks - w + W - 1u) / W : 0u;
+            uint32_t const mine = my_chunks * 64u;  // slots; those past n have no ray
             uint32_t next = 0;
             bool busy = false;
             uint32_t pid = 0;
@@ -650,8 +644,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                     uint32_t const rank = (uint32_t) __builtin_popcountll(idle & below);
                     if (!busy && rank < take) {
                         uint32_t const j = next + rank;
-                        uint32_t const run_slots = kRefillRun * 64u;
-                        uint32_t const i = (w + (j / run_slots) * W) * run_slots + j % run_slots;
+                        uint32_t const i = (w + (j / 64u) * W) * 64u + j % 64u;
                         f3 o, d;
                         float t_limit;
                         if (i < n && fetch(i, pid, o, d, t_limit)) {
