@@ -165,200 +165,87 @@ struct pair_result {
     hit_result best;
 };
 
-// ANY = false: closest hit (best is filled, returns whether anything was hit).
-// ANY = true : occlusion query over (0, t_limit]; returns on the first hit.
-// Lanes with active == false skip the walk (their ray does not exist).
-// CACHED: nodes / instance records below stk.cached_* are read from LDS, where a fetch
-// that differs per lane costs a few cycles instead of one cache-line lookup per lane in the
-// vector memory pipeline (which is what bounds this walk), and the stack holds as many
-// entries as the scene needs instead of kFastLdsEntries.
-template <bool ANY, bool COUNT, bool CACHED = false>
-RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, f3 origin,
-    f3 direction, float t_limit, hit_result& best, trace_counters& cnt) {
-    uint32_t sp = 0;
-    auto slot = [&](uint32_t entry) -> uint32_t {
-        // never wraps: the builder bounds the depth and upload checks it against the stack
-        return entry * 64u;
-    };
-    auto push = [&](int32_t v) {
-        stk.lds[slot(sp)] = (uint32_t) v;
+// One walk of the rebuilt structure: a ray, its cursor and its stack pointer (the stack itself
+// lives in LDS, fast_stack).  ANY = false: closest hit (best is filled); ANY = true: occlusion
+// query over (0, t_limit], over at the first hit.  COPIES: nodes / instance records below
+// stk.cached_* are read from the workgroup's LDS copy, where a fetch that differs per lane costs
+// a few cycles instead of one cache-line lookup per lane in the vector memory pipeline.
+//
+// The walk is a sequence of steps of three kinds, chosen by the cursor `cur`: an inner node
+// (cur >= 0: test the four child boxes, go to the nearest hit child, push the others farthest
+// first - or pop), a TLAS leaf (cur < 0 outside an instance: enter the instance, i.e. switch
+// to the object-space ray and push a marker) and a BLAS leaf (cur < 0 inside an instance: test
+// its triangles and pop; the cursor can also hold the REST of a leaf).  Popping the marker
+// switches back to the world-space ray.  cur == kDone: nothing left.  The callers differ only
+// in which lanes of a wave step together (trace_fast, fast_walk::round, wf_extend_kernel);
+// a ray's own sequence of steps, and so every result, is the same in all of them.
+template <bool ANY, bool COUNT, bool COPIES>
+struct fast_walk {
+    f3 origin, direction;
+    slab_ray world_slab, slab;
+    tri_ray tr;
+    float t_max;
+    hit_result best;
+    uint32_t current_instance;
+    uint32_t sp;
+    int32_t cur;
+    bool in_blas;
+    bool found;
+
+    // no leaf code equals it (the builder refuses scenes with 2^28 triangles or more)
+    static constexpr int32_t kDone = (int32_t) 0x80000000u;
+
+    RT_DEV void start(scene_dev const& sc, f3 o, f3 d, float t_limit) {
+        origin = o;
+        direction = d;
+        world_slab = make_slab_ray(o, d);
+        slab = world_slab;
+        tr = tri_ray{};  // triangles are tested inside instances only: set up on entry
+        t_max = t_limit;
+        found = false;
+        best.instance = RT_HIP_MISS;
+        best.triangle = RT_HIP_MISS;
+        best.b0 = best.b1 = best.b2 = 0.0f;
+        best.t = kInfinity;
+        current_instance = 0;
+        sp = 0;
+        cur = sc.wide_tlas_root;
+        in_blas = false;
+    }
+
+    // (never overflows: the builder bounds the depth and upload checks it against the stack)
+    RT_DEV void push(fast_stack const& stk, trace_counters& cnt, int32_t v) {
+        stk.lds[sp * 64u] = (uint32_t) v;
         ++sp;
         if (COUNT) {
             cnt.max_stack = max(cnt.max_stack, sp);
         }
-    };
-    auto pop = [&]() -> int32_t {
-        --sp;
-        return (int32_t) stk.lds[slot(sp)];
-    };
-
-    float t_max = t_limit;
-    bool found = false;
-    // Ray set-up runs for the whole wave at once, outside the divergent loop.
-    slab_ray const world_slab = make_slab_ray(origin, direction);
-    slab_ray slab = world_slab;
-    // triangles are tested inside instances only, with the object-space ray set up on entry
-    tri_ray tr{};
-    uint32_t current_instance = 0;
-    int32_t cur = sc.wide_tlas_root;
-    bool in_blas = false;
-    if (!active) {
-        return false;
     }
 
-    if constexpr (!CACHED) {
-        // The fused kernels: one step of whatever kind per trip of the loop.  (The descent
-        // loop below measured 20 % slower there: with two waves per SIMD the lanes idling
-        // through other lanes' descents cost more than the shared leaf rounds save.)
-        for (;;) {
-            if (cur >= 0) {
-                float4 lx, ly, lz, hx, hy, hz, kids;
-                if (kTraceCopies && CACHED && (uint32_t) cur < stk.cached_nodes) {
-                    lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
-                    lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
-                } else {
-                    const float4* np = quads_at(sc.wide_nodes, (uint32_t) cur);
-                    lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
-                }
-                if (COUNT) {
-                    ++cnt.nodes;
-                }
-                int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y),
-                    __float_as_int(kids.z), __float_as_int(kids.w)};
-                float key[4];
-                float const miss = kInfinity * 2.0f;  // beyond any entry distance
-                {
-                    float e, x;
-                    slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
-                    key[0] = e <= x ? e : miss;
-                    slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
-                    key[1] = e <= x ? e : miss;
-                    slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
-                    key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
-                    slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
-                    key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
-                }
-                // nearest first: sort the four (distance, child) pairs, misses go last
-                auto order = [&](int i, int j) {
-                    bool const swap = key[j] < key[i];
-                    float const ki = swap ? key[j] : key[i];
-                    float const kj = swap ? key[i] : key[j];
-                    int32_t const ri = swap ? ref[j] : ref[i];
-                    int32_t const rj = swap ? ref[i] : ref[j];
-                    key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
-                };
-                order(0, 1);
-                order(2, 3);
-                order(0, 2);
-                order(1, 3);
-                order(1, 2);
-                if (key[0] < miss) {
-                    if (key[3] < miss) {
-                        push(ref[3]);
-                    }
-                    if (key[2] < miss) {
-                        push(ref[2]);
-                    }
-                    if (key[1] < miss) {
-                        push(ref[1]);
-                    }
-                    cur = ref[0];
-                    continue;
-                }
-            } else if (!in_blas) {
-                // TLAS leaf: exactly one instance.  Enter its BLAS.
-                uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-                const float4* ip = quads_at(sc.wide_instances, rec_index);
-                float4 r0, r1, r2, r3;
-                if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
-                    lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
-                    r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
-                } else {
-                    r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
-                }
-                if (COUNT) {
-                    ++cnt.instances;
-                }
-                // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
-                f3 o, d;
-                o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
-                o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
-                o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
-                d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
-                d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
-                d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
-                slab = make_slab_ray(o, d);
-                tr = make_tri_ray(o, d);
-                current_instance = (uint32_t) __float_as_int(r3.y);
-                push(kInstanceMarker);
-                in_blas = true;
-                cur = __float_as_int(r3.x);
-                continue;
-            } else {
-                // BLAS leaf: 1..8 triangles.
-                uint32_t const code = (uint32_t) ~cur;
-                uint32_t const first = code >> 3;
-                uint32_t const count = (code & 7u) + 1u;
-                for (uint32_t k = 0; k < count; ++k) {
-                    const float4* tp = quads_at(sc.wide_tris, first + k);
-                    float4 const va = tp[0], vb = tp[1], vc = tp[2];
-                    if (COUNT) {
-                        ++cnt.tris;
-                    }
-                    float b0, b1, b2, th;
-                    if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z),
-                            mk3(vc.x, vc.y, vc.z), tr, t_max, b0, b1, b2, th,
-                            sc.wide_lists_degenerate != 0u)) {
-                        if (ANY) {
-                            return true;
-                        }
-                        t_max = th;
-                        found = true;
-                        best.instance = current_instance;
-                        best.triangle = (uint32_t) __float_as_int(va.w);
-                        best.b0 = b0;
-                        best.b1 = b1;
-                        best.b2 = b2;
-                        best.t = th;
-                    }
-                }
-            }
-            // pop the next subtree; leaving an instance restores the world-space ray
-            for (;;) {
-                if (sp == 0) {
-                    return found;
-                }
-                cur = pop();
-                if (cur != kInstanceMarker) {
-                    break;
-                }
-                in_blas = false;
-                slab = world_slab;
-            }
-        }
-    }
-    // "Nothing left" value of `cur`: no leaf code equals it (the builder refuses scenes with
-    // 2^28 triangles or more).
-    constexpr int32_t kDone = (int32_t) 0x80000000u;
     // Pops the next subtree; leaving an instance restores the world-space ray.
-    auto next_subtree = [&]() {
+    RT_DEV void next_subtree(fast_stack const& stk) {
         for (;;) {
             if (sp == 0) {
                 cur = kDone;
                 return;
             }
-            cur = pop();
+            --sp;
+            cur = (int32_t) stk.lds[sp * 64u];
             if (cur != kInstanceMarker) {
                 return;
             }
             in_blas = false;
             slab = world_slab;
         }
-    };
-    // One inner node: goes to the nearest hit child (pushing the others) or pops.
-    auto node_step = [&]() {
+    }
+
+    // POP = false: a step that ends with nothing to go on with does not pop the next subtree
+    // itself but returns true, so that the caller can pop once for lanes coming from node
+    // steps and from leaves alike (the pop waits for an LDS read).
+    template <bool POP = true>
+    RT_DEV bool node_step(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         float4 lx, ly, lz, hx, hy, hz, kids;
-        if (kTraceCopies && CACHED && (uint32_t) cur < stk.cached_nodes) {
+        if (kTraceCopies && COPIES && (uint32_t) cur < stk.cached_nodes) {
             lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
             lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
             if (COUNT) {
@@ -403,217 +290,6 @@ RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, 
         order(1, 2);
         if (key[0] < miss) {
             if (key[3] < miss) {
-                push(ref[3]);
-            }
-            if (key[2] < miss) {
-                push(ref[2]);
-            }
-            if (key[1] < miss) {
-                push(ref[1]);
-            }
-            cur = ref[0];
-        } else {
-            next_subtree();
-        }
-    };
-
-    for (;;) {
-        if (cur >= 0) {
-            // The pipeline's trace kernel lets every lane descend until it holds a leaf or has
-            // nothing left before any lane enters an instance or tests triangles: lanes then
-            // wait for the other kinds of step once per round, not on every step.
-            do {
-                node_step();
-            } while (cur >= 0 && (kDescentMin == 0u ||
-                                     (uint32_t) __builtin_popcountll(__ballot(cur >= 0)) >= kDescentMin));
-        }
-        if (cur == kDone) {
-            return found;
-        }
-        if (kDescentMin != 0u && cur >= 0) {
-            continue;  // still descending: the other lanes' leaves came first
-        }
-        if (!in_blas) {
-            // TLAS leaf: exactly one instance.  Enter its BLAS.
-            uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-            const float4* ip = quads_at(sc.wide_instances, rec_index);
-            float4 r0, r1, r2, r3;
-            if (kTraceCopies && CACHED && rec_index < stk.cached_instances) {
-                lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
-                r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
-                if (COUNT) {
-                    ++cnt.lds_instances;
-                }
-            } else {
-                r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
-            }
-            if (COUNT) {
-                ++cnt.instances;
-                cnt.instance_wave_steps += first_active_lane();
-            }
-            // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
-            f3 o, d;
-            o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
-            o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
-            o.z = ((r0.z * origin.x + r1.y * origin.y) + r2.x * origin.z) + r2.w * 1.0f;
-            d.x = ((r0.x * direction.x + r0.w * direction.y) + r1.z * direction.z) + r2.y * 0.0f;
-            d.y = ((r0.y * direction.x + r1.x * direction.y) + r1.w * direction.z) + r2.z * 0.0f;
-            d.z = ((r0.z * direction.x + r1.y * direction.y) + r2.x * direction.z) + r2.w * 0.0f;
-            slab = make_slab_ray(o, d);
-            tr = make_tri_ray(o, d);
-            current_instance = (uint32_t) __float_as_int(r3.y);
-            push(kInstanceMarker);
-            in_blas = true;
-            cur = __float_as_int(r3.x);
-            continue;
-        }
-        // BLAS leaf: 1..8 triangles.
-        uint32_t const code = (uint32_t) ~cur;
-        uint32_t const first = code >> 3;
-        uint32_t const count = (code & 7u) + 1u;
-        uint32_t k = 0;
-        do {
-            const float4* tp = quads_at(sc.wide_tris, first + k);
-            float4 const va = tp[0], vb = tp[1], vc = tp[2];
-            if (COUNT) {
-                ++cnt.tris;
-                cnt.tri_wave_steps += first_active_lane();
-            }
-            float b0, b1, b2, th;
-            if (hit_triangle(mk3(va.x, va.y, va.z), mk3(vb.x, vb.y, vb.z), mk3(vc.x, vc.y, vc.z),
-                    tr, t_max, b0, b1, b2, th, sc.wide_lists_degenerate != 0u)) {
-                if (ANY) {
-                    return true;
-                }
-                t_max = th;
-                found = true;
-                best.instance = current_instance;
-                best.triangle = (uint32_t) __float_as_int(va.w);
-                best.b0 = b0;
-                best.b1 = b1;
-                best.b2 = b2;
-                best.t = th;
-            }
-            ++k;
-        } while (k < count && (kLeafMin == 0u ||
-                                  (uint32_t) __builtin_popcountll(__ballot(k < count)) >= kLeafMin));
-        if (k < count) {
-            cur = (int32_t) ~(((first + k) << 3) | (count - k - 1u));  // the rest of the leaf
-        } else {
-            next_subtree();
-        }
-    }
-}
-
-// The same walk as trace_fast<.., CACHED = true>, cut into resumable rounds: start() takes a
-// ray, round() runs one round for the wave (see there) and says whether this lane's walk is
-// over.  A wave that keeps one walk per lane can hand a finished lane its next ray while the
-// other lanes are still walking (wf_extend_kernel).  Each ray's own sequence of steps - the
-// visiting order and the arithmetic - is that of trace_fast; only which lanes step together
-// differs, which no result depends on.
-template <bool ANY, bool COUNT>
-struct fast_walk {
-    f3 origin, direction;
-    slab_ray world_slab, slab;
-    tri_ray tr;
-    float t_max;
-    hit_result best;
-    uint32_t current_instance;
-    uint32_t sp;
-    int32_t cur;
-    bool in_blas;
-    bool found;
-
-    static constexpr int32_t kDone = (int32_t) 0x80000000u;
-
-    RT_DEV void start(scene_dev const& sc, f3 o, f3 d, float t_limit) {
-        origin = o;
-        direction = d;
-        world_slab = make_slab_ray(o, d);
-        slab = world_slab;
-        tr = tri_ray{};  // triangles are tested inside instances only: set up on entry
-        t_max = t_limit;
-        found = false;
-        best.instance = RT_HIP_MISS;
-        best.triangle = RT_HIP_MISS;
-        best.b0 = best.b1 = best.b2 = 0.0f;
-        best.t = kInfinity;
-        current_instance = 0;
-        sp = 0;
-        cur = sc.wide_tlas_root;
-        in_blas = false;
-    }
-
-    RT_DEV void push(fast_stack const& stk, trace_counters& cnt, int32_t v) {
-        stk.lds[sp * 64u] = (uint32_t) v;
-        ++sp;
-        if (COUNT) {
-            cnt.max_stack = max(cnt.max_stack, sp);
-        }
-    }
-
-    RT_DEV void next_subtree(fast_stack const& stk) {
-        for (;;) {
-            if (sp == 0) {
-                cur = kDone;
-                return;
-            }
-            --sp;
-            cur = (int32_t) stk.lds[sp * 64u];
-            if (cur != kInstanceMarker) {
-                return;
-            }
-            in_blas = false;
-            slab = world_slab;
-        }
-    }
-
-    RT_DEV void node_step(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
-        float4 lx, ly, lz, hx, hy, hz, kids;
-        if (kTraceCopies && (uint32_t) cur < stk.cached_nodes) {
-            lds_quads const lp = lds_view(stk.node_cache) + kWideNodeQuads * (uint32_t) cur;
-            lx = lp[0], ly = lp[1], lz = lp[2], hx = lp[3], hy = lp[4], hz = lp[5], kids = lp[6];
-            if (COUNT) {
-                ++cnt.lds_nodes;
-            }
-        } else {
-            const float4* np = quads_at(sc.wide_nodes, (uint32_t) cur);
-            lx = np[0], ly = np[1], lz = np[2], hx = np[3], hy = np[4], hz = np[5], kids = np[6];
-        }
-        if (COUNT) {
-            ++cnt.nodes;
-            cnt.node_wave_steps += first_active_lane();
-        }
-        int32_t ref[4] = {__float_as_int(kids.x), __float_as_int(kids.y), __float_as_int(kids.z),
-            __float_as_int(kids.w)};
-        float key[4];
-        float const miss = kInfinity * 2.0f;
-        {
-            float e, x;
-            slab_box(slab, lx.x, ly.x, lz.x, hx.x, hy.x, hz.x, t_max, e, x);
-            key[0] = e <= x ? e : miss;
-            slab_box(slab, lx.y, ly.y, lz.y, hx.y, hy.y, hz.y, t_max, e, x);
-            key[1] = e <= x ? e : miss;
-            slab_box(slab, lx.z, ly.z, lz.z, hx.z, hy.z, hz.z, t_max, e, x);
-            key[2] = (e <= x && ref[2] != kNoChild) ? e : miss;
-            slab_box(slab, lx.w, ly.w, lz.w, hx.w, hy.w, hz.w, t_max, e, x);
-            key[3] = (e <= x && ref[3] != kNoChild) ? e : miss;
-        }
-        auto order = [&](int i, int j) {
-            bool const swap = key[j] < key[i];
-            float const ki = swap ? key[j] : key[i];
-            float const kj = swap ? key[i] : key[j];
-            int32_t const ri = swap ? ref[j] : ref[i];
-            int32_t const rj = swap ? ref[i] : ref[j];
-            key[i] = ki, key[j] = kj, ref[i] = ri, ref[j] = rj;
-        };
-        order(0, 1);
-        order(2, 3);
-        order(0, 2);
-        order(1, 3);
-        order(1, 2);
-        if (key[0] < miss) {
-            if (key[3] < miss) {
                 push(stk, cnt, ref[3]);
             }
             if (key[2] < miss) {
@@ -623,28 +299,33 @@ struct fast_walk {
                 push(stk, cnt, ref[1]);
             }
             cur = ref[0];
-        } else {
+            return false;
+        }
+        if (POP) {
             next_subtree(stk);
         }
+        return true;
     }
 
+    // TLAS leaf: exactly one instance.  Enters its BLAS.
     RT_DEV void enter_instance(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         uint32_t const rec_index = ((uint32_t) ~cur) >> 3;
-        const float4* ip = quads_at(sc.wide_instances, rec_index);
         float4 r0, r1, r2, r3;
-        if (kTraceCopies && rec_index < stk.cached_instances) {
+        if (kTraceCopies && COPIES && rec_index < stk.cached_instances) {
             lds_quads const lp = lds_view(stk.instance_cache) + 4u * rec_index;
             r0 = lp[0], r1 = lp[1], r2 = lp[2], r3 = lp[3];
             if (COUNT) {
                 ++cnt.lds_instances;
             }
         } else {
+            const float4* ip = quads_at(sc.wide_instances, rec_index);
             r0 = ip[0], r1 = ip[1], r2 = ip[2], r3 = ip[3];
         }
         if (COUNT) {
             ++cnt.instances;
             cnt.instance_wave_steps += first_active_lane();
         }
+        // m[col*3 + row]: r0 = (m00 m01 m02 m10) r1 = (m11 m12 m20 m21) r2 = (m22 m30 m31 m32)
         f3 o, d;
         o.x = ((r0.x * origin.x + r0.w * origin.y) + r1.z * origin.z) + r2.y * 1.0f;
         o.y = ((r0.y * origin.x + r1.x * origin.y) + r1.w * origin.z) + r2.z * 1.0f;
@@ -660,9 +341,12 @@ struct fast_walk {
         cur = __float_as_int(r3.x);
     }
 
-    // Tests triangles of the leaf in `cur` until the leaf is done or fewer than kLeafMin lanes
-    // still have some left; an occlusion walk that finds a hit is over (cur = kDone).
-    RT_DEV void test_leaf(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
+    // BLAS leaf (1..8 triangles, or the rest of one): tests triangles until the leaf is done
+    // or - leaf_min > 0 - fewer than leaf_min of the lanes in here still have some left, in
+    // which case the cursor keeps the rest.  An occlusion walk that finds a hit is over.
+    template <bool POP = true>
+    RT_DEV bool test_leaf(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt,
+        uint32_t leaf_min) {
         uint32_t const code = (uint32_t) ~cur;
         uint32_t const first = code >> 3;
         uint32_t const count = (code & 7u) + 1u;
@@ -693,35 +377,46 @@ struct fast_walk {
             }
             ++k;
         } while (!stop && k < count &&
-                 (kLeafMin == 0u ||
-                     (uint32_t) __builtin_popcountll(__ballot(k < count)) >= kLeafMin));
+                 (leaf_min == 0u ||
+                     (uint32_t) __builtin_popcountll(__ballot(k < count)) >= leaf_min));
         if (stop) {
             cur = kDone;
-        } else if (k < count) {
+            return false;
+        }
+        if (k < count) {
             cur = (int32_t) ~(((first + k) << 3) | (count - k - 1u));  // the rest of the leaf
-        } else {
+            return false;
+        }
+        if (POP) {
             next_subtree(stk);
+        }
+        return true;
+    }
+
+    // Node steps until this lane holds a leaf or has nothing left - or, descent_min > 0, until
+    // fewer than descent_min of the lanes in here still descend.
+    RT_DEV void descend(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt,
+        uint32_t descent_min) {
+        while (cur >= 0) {
+            node_step(sc, stk, cnt);
+            if (descent_min != 0u &&
+                (uint32_t) __builtin_popcountll(__ballot(cur >= 0)) < descent_min) {
+                break;
+            }
         }
     }
 
-    // One round; returns true when the walk is over.  A kind of step runs when enough of the
+    // One round of a wave that keeps a walk per lane (wf_extend_kernel's refilling loop);
+    // returns true when this lane's walk is over.  A kind of step runs when enough of the
     // wave's lanes wait for it (node steps: kDescentMin, instance entries: kInstanceMin,
-    // triangles: kLeafStart); when no kind has enough, the one most lanes wait for runs.
-    // Must be called by every lane of the wave that has a walk, together.
+    // triangles: kLeafStart); when no kind has enough, the one most lanes wait for runs, so
+    // every round makes progress.  Must be called by every lane that has a walk, together.
     RT_DEV bool round(scene_dev const& sc, fast_stack const& stk, trace_counters& cnt) {
         auto lanes = [](bool v) { return (uint32_t) __builtin_popcountll(__ballot(v)); };
-        auto descend = [&]() {
-            while (cur >= 0) {
-                node_step(sc, stk, cnt);
-                if (kDescentMin != 0u && lanes(cur >= 0) < kDescentMin) {
-                    break;
-                }
-            }
-        };
         uint32_t const n_node = lanes(cur >= 0);
         bool const ran = n_node >= max(kDescentMin, 1u);
         if (ran) {
-            descend();
+            descend(sc, stk, cnt, kDescentMin);
         }
         bool const at_instance = cur < 0 && cur != kDone && !in_blas;
         bool const at_leaf = cur < 0 && cur != kDone && in_blas;
@@ -731,7 +426,7 @@ struct fast_walk {
         bool run_leaf = n_leaf >= max(kLeafStart, 1u);
         if (!ran && !run_instance && !run_leaf) {
             if (n_node >= n_instance && n_node >= n_leaf) {
-                descend();
+                descend(sc, stk, cnt, kDescentMin);
             } else if (n_instance >= n_leaf) {
                 run_instance = true;
             } else {
@@ -742,11 +437,60 @@ struct fast_walk {
             enter_instance(sc, stk, cnt);
         }
         if (run_leaf && at_leaf) {
-            test_leaf(sc, stk, cnt);
+            test_leaf(sc, stk, cnt, kLeafMin);
         }
         return cur == kDone;
     }
 };
+
+// One ray per lane, from start to end.  Lanes with active == false skip the walk (their ray
+// does not exist); the ray set-up runs for the whole wave at once, outside the divergent loop.
+// CACHED = false (the fused kernels, two waves per SIMD): one step of whatever kind per trip
+// of the loop.  CACHED = true (the pipeline's trace kernel, fixed chunks of 64 rays): every
+// lane descends until it holds a leaf or has nothing left - or only kDescentMin lanes still
+// descend - before any lane enters an instance or tests triangles, so lanes wait for the other
+// kinds of step once per round, not on every step.  (That loop measured 20 % slower in the
+// fused kernels: there the lanes idling through other lanes' descents cost more than the
+// shared leaf rounds save.)
+template <bool ANY, bool COUNT, bool CACHED = false>
+RT_DEV bool trace_fast(scene_dev const& sc, fast_stack const& stk, bool active, f3 origin,
+    f3 direction, float t_limit, hit_result& best, trace_counters& cnt) {
+    fast_walk<ANY, COUNT, CACHED> w;
+    w.start(sc, origin, direction, t_limit);
+    if (!active) {
+        return false;
+    }
+    for (;;) {
+        if constexpr (!CACHED) {
+            if (w.cur >= 0) {
+                if (!w.template node_step<false>(sc, stk, cnt)) {
+                    continue;
+                }
+            } else if (!w.in_blas) {
+                w.enter_instance(sc, stk, cnt);
+                continue;
+            } else if (!w.template test_leaf<false>(sc, stk, cnt, 0u)) {
+                return true;  // (only an occlusion walk's leaf ends without a pop: a hit)
+            }
+            w.next_subtree(stk);
+        } else {
+            w.descend(sc, stk, cnt, kDescentMin);
+            if (w.cur < 0 && w.cur != w.kDone) {
+                if (!w.in_blas) {
+                    w.enter_instance(sc, stk, cnt);
+                } else {
+                    w.test_leaf(sc, stk, cnt, kLeafMin);
+                }
+            }
+        }
+        if (w.cur == w.kDone) {
+            if (!ANY) {
+                best = w.best;
+            }
+            return w.found;
+        }
+    }
+}
 
 template <bool COUNT>
 RT_DEV void trace_pair_fast(scene_dev const& sc, fast_stack const& stk, ray_pair const& rp,

@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 }
             }
         };
-        run(fast_walk<false, COUNT>{}, n_closest,
+        run(fast_walk<false, COUNT, true>{}, n_closest,
             [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
                 t_limit = kInfinity;
                 if (FIRST) {
@@ -679,13 +679,13 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 d = mk3(rd.x, rd.y, rd.z);
                 return true;
             },
-            [&](uint32_t pid, fast_walk<false, COUNT> const& wk) {
+            [&](uint32_t pid, fast_walk<false, COUNT, true> const& wk) {
                 stream_store(&p.hit0[pid],
                     make_float4(__uint_as_float(wk.found ? wk.best.instance : RT_HIP_MISS),
                         __uint_as_float(wk.best.triangle), wk.best.b0, wk.best.b1));
                 stream_store(&p.hit1[pid], make_float2(wk.best.b2, wk.best.t));
             });
-        run(fast_walk<true, COUNT>{}, n_shadow,
+        run(fast_walk<true, COUNT, true>{}, n_shadow,
             [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
                 pid = stream_load(&q_shadow[i]);
                 float4 const ro = stream_load(&p.sh_o[pid]);
@@ -695,7 +695,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 t_limit = ro.w;
                 return true;
             },
-            [&](uint32_t pid, fast_walk<true, COUNT> const& wk) {
+            [&](uint32_t pid, fast_walk<true, COUNT, true> const& wk) {
                 stream_store(&p.occluded[pid], wk.found ? 1u : 0u);
             });
     } else
