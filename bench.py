@@ -70,6 +70,8 @@ def parse_args():
     ap.add_argument("--binning", choices=["auto", "on", "off"], default="auto",
                     help="regroup the ray queues before each trace launch: decided per scene by "
                          "the library from one untimed call before warm-up (auto), or forced")
+    ap.add_argument("--refill", choices=["auto", "on", "off"], default="auto",
+                    help="trace launches refill finished lanes / take fixed chunks (auto: measured)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-work-counters", action="store_true",
                     help="skip the untimed counting call (roofline becomes null)")
@@ -202,18 +204,11 @@ def count_work(hip, host, sc, cam, args, tile, accel, device_index, first_pass, 
     trace launches of this build fetch per ray, how much of it their LDS copy serves and how many
     lanes their steps keep in use (`refill`: hand out rays the way the timed steps did)."""
     flags = hip.FLAG_COUNT_NODES | hip.FLAG_NO_BIN_RAYS  # the order of the queues changes no count
+    flags |= hip.FLAG_TRACE_REFILL if refill else hip.FLAG_TRACE_CHUNKS
     r = hip.HipRenderer(args.width, args.height, args.max_depth, tile, device=device_index,
                         accel=accel, flags=flags)
     try:
-        before = os.environ.get("RT_HIP_TRACE_REFILL")
-        os.environ["RT_HIP_TRACE_REFILL"] = "1" if refill else "0"   # read at upload
-        try:
-            r.upload_scene(sc.desc)
-        finally:
-            if before is None:
-                del os.environ["RT_HIP_TRACE_REFILL"]
-            else:
-                os.environ["RT_HIP_TRACE_REFILL"] = before
+        r.upload_scene(sc.desc)
         r.upload_seeds(seeds_row, first_pass)
         r.clear()
         r.render(cam, first_pass, args.spp_per_step)
@@ -261,6 +256,7 @@ def main():
     accel = hip.ACCEL_REBUILT if args.accel == "rebuilt" else hip.ACCEL_REFERENCE
     flags = hip.FLAG_FUSED if args.pipeline == "fused" else hip.FLAG_TIME_KERNELS
     flags |= {"auto": 0, "on": hip.FLAG_BIN_RAYS, "off": hip.FLAG_NO_BIN_RAYS}[args.binning]
+    flags |= {"auto": 0, "on": hip.FLAG_TRACE_REFILL, "off": hip.FLAG_TRACE_CHUNKS}[args.refill]
     r = hip.HipRenderer(args.width, args.height, args.max_depth, tile, device=local_rank,
                         accel=accel, flags=flags)
     r.upload_scene(sc.desc)

@@ -73,7 +73,14 @@ enum {
      * (:431-436) becomes the density of that distribution, for the light sample and for the
      * MIS weight of BSDF-sampled rays that reach the sky alike.  Without the flag, and for a
      * sky without a map, sampling is the reference's. */
-    RT_HIP_FLAG_SKY_IMPORTANCE = 32u
+    RT_HIP_FLAG_SKY_IMPORTANCE = 32u,
+    /* How the pipeline's trace launches hand out rays (see rt_hip_trace_refill): every bounce
+     * with refilled lanes, or every bounce in fixed chunks of 64 rays.  Default (neither flag):
+     * measured per uploaded scene and bounce.  Images are bit-identical either way; with both
+     * policies forced (these and the binning flags) a renderer's throughput no longer depends
+     * on a measurement. */
+    RT_HIP_FLAG_TRACE_REFILL = 64u,
+    RT_HIP_FLAG_TRACE_CHUNKS = 128u
 };
 
 enum {

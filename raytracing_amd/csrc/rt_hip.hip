@@ -1583,6 +1583,10 @@ int rt_hip_create(const rt_hip_config* config, rt_hip_renderer** out) {
         if (c.accel > RT_HIP_ACCEL_REBUILT) {
             throw std::runtime_error("create: unknown accel mode");
         }
+        if (((config->flags & RT_HIP_FLAG_BIN_RAYS) && (config->flags & RT_HIP_FLAG_NO_BIN_RAYS)) ||
+            ((config->flags & RT_HIP_FLAG_TRACE_REFILL) && (config->flags & RT_HIP_FLAG_TRACE_CHUNKS))) {
+            throw std::runtime_error("create: flags that force a policy on and off together");
+        }
         int device_count = 0;
         HIP_CHECK(hipGetDeviceCount(&device_count));
         if (device_count == 0) {
@@ -1740,7 +1744,11 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         r->refill_ms[0] = r->refill_ms[1] = -1.0;
         r->refill_trip.clear();
         r->bin_candidates = false;
-        if (char const* const v = getenv("RT_HIP_TRACE_REFILL")) {  // experiments: force it
+        if (r->cfg.flags & RT_HIP_FLAG_TRACE_REFILL) {
+            r->refill = RT_HIP_REFILL_ON;
+        } else if (r->cfg.flags & RT_HIP_FLAG_TRACE_CHUNKS) {
+            r->refill = RT_HIP_REFILL_OFF;
+        } else if (char const* const v = getenv("RT_HIP_TRACE_REFILL")) {  // experiments
             r->refill = atoi(v) != 0 ? RT_HIP_REFILL_ON : RT_HIP_REFILL_OFF;
         }
         r->bin_trip.clear();

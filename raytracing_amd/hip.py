@@ -22,6 +22,8 @@ FLAG_TIME_KERNELS = 4
 FLAG_BIN_RAYS = 8
 FLAG_NO_BIN_RAYS = 16
 FLAG_SKY_IMPORTANCE = 32
+FLAG_TRACE_REFILL = 64
+FLAG_TRACE_CHUNKS = 128
 BINNING_UNDECIDED, BINNING_OFF, BINNING_ON = 0, 1, 2
 REFILL_UNDECIDED, REFILL_OFF, REFILL_ON = 0, 1, 2
 KERNEL_RENDER, KERNEL_EXTEND, KERNEL_SHADE = 0, 1, 2

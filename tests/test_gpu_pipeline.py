@@ -154,18 +154,20 @@ def test_ray_binning_is_decided_by_measurement(cornell, staircase):
     assert all(state in (hip.BINNING_ON, hip.BINNING_OFF) for state, _ in outcome.values())
 
 
-@pytest.mark.parametrize("refill", ["0", "1"])
+REFILL = [hip.FLAG_TRACE_CHUNKS, hip.FLAG_TRACE_REFILL]
+
+
+@pytest.mark.parametrize("refill", REFILL)
 @pytest.mark.parametrize("binning", BINNING)
-def test_trace_launch_hands_out_rays_either_way(monkeypatch, staircase, binning, refill):
+def test_trace_launch_hands_out_rays_either_way(staircase, binning, refill):
     """The trace launch gives a wave fixed chunks of 64 rays, or gives each lane that has
-    finished its ray the next one.  Either way (forced here through the experiment knob, read
-    when a scene is uploaded) every ray is traced exactly once: image and work counters equal
-    the fused kernel's."""
-    monkeypatch.setenv("RT_HIP_TRACE_REFILL", refill)
+    finished its ray the next one.  Either way (forced here by flag) every ray is traced
+    exactly once: image and work counters equal the fused kernel's."""
     w, h, md, tile, spp = 320, 184, 7, (64, 46), 5
     fused = run(staircase, w, h, md, tile, spp, hip.ACCEL_REBUILT,
                 hip.FLAG_FUSED | hip.FLAG_COUNT_NODES)
-    piped = run(staircase, w, h, md, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_COUNT_NODES | binning)
+    piped = run(staircase, w, h, md, tile, spp, hip.ACCEL_REBUILT,
+                hip.FLAG_COUNT_NODES | binning | refill)
     assert same(fused[0], piped[0])
     for k in COUNTERS:
         assert fused[2][k] == piped[2][k], k
@@ -214,13 +216,13 @@ def test_trace_refill_is_decided_by_measurement(hyperion):
     assert same(auto, want)
 
 
-@pytest.mark.parametrize("refill", ["0", "1"])
-def test_trace_work_counters(monkeypatch, hyperion, refill):
+@pytest.mark.parametrize("refill", REFILL)
+def test_trace_work_counters(hyperion, refill):
     """rt_hip_trace_work: the fetch counts repeat the statistics, and the wave-step counters
     bound them - a wave step serves between 1 and 64 lanes."""
-    monkeypatch.setenv("RT_HIP_TRACE_REFILL", refill)
     w, h, md, tile, spp = 640, 360, 7, (64, 36), 4
-    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=hip.FLAG_COUNT_NODES)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT,
+                        flags=hip.FLAG_COUNT_NODES | refill)
     try:
         r.upload_scene(hyperion.desc)
         r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
@@ -240,6 +242,27 @@ def test_trace_work_counters(monkeypatch, hyperion, refill):
     # instance entries of the finishing kernel are not told apart: only the lower bound holds
     assert 0 < work["instance_wave_steps"] <= work["instance_records"]
     assert work["node_bytes"] > 0 and work["triangle_bytes"] > 0 and work["instance_bytes"] > 0
+
+
+def test_forced_trace_policies_are_not_measured(cornell):
+    w, h, md, tile, spp = 640, 800, 3, (64, 80), 16
+    flags = hip.FLAG_NO_BIN_RAYS | hip.FLAG_TRACE_CHUNKS
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=flags)
+    try:
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, 2 * spp, r.tile_count))
+        r.clear()
+        for call in range(2):
+            r.render(cornell.camera(w, h), call * spp, spp)
+            r.read_accum()
+        assert r.ray_binning() == (hip.BINNING_OFF, 0.0)
+        assert r.trace_refill() == (hip.REFILL_OFF, -1.0, -1.0, 0)
+    finally:
+        r.close()
+    for both in (hip.FLAG_BIN_RAYS | hip.FLAG_NO_BIN_RAYS,
+                 hip.FLAG_TRACE_REFILL | hip.FLAG_TRACE_CHUNKS):
+        with pytest.raises(RuntimeError, match="on and off together"):
+            hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT, flags=both)
 
 
 def test_trip_counts_and_kernel_times(hyperion):
