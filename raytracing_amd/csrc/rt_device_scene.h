@@ -57,6 +57,10 @@ struct instance_rec {
 };
 static_assert(sizeof(instance_rec) == 64, "instance_rec is one 64-byte line");
 
+struct normal_matrix {
+    float4 c0, c1, c2;
+};
+
 struct scene_dev {
     const rt_bvh_node* tlas;
     const rt_bvh_node* blas;
@@ -65,6 +69,10 @@ struct scene_dev {
     const rt_triangle* triangles;
     const rt_mat4* transforms;
     const rt_mat4* inverse_transforms;
+    // per transform: the inverse of its upper 3x3 as three columns (w unused), which carries
+    // normals to world space - computed once per scene with the shading code's own inverse33
+    // instead of once per hit (megakernel_raytracer.comp:299 and :474 do it per hit)
+    const normal_matrix* normal_matrices;
     const rt_material* materials;
     const rt_light* lights;
     const texture_dev* textures;
@@ -102,6 +110,7 @@ enum : uint32_t {
     kTableTextures,
     kTableInstances,
     kTableTransforms,
+    kTableNormalMatrices,
     kTableCount,
 };
 constexpr uint32_t kNotStaged = 0xFFFFFFFFu;
@@ -122,6 +131,7 @@ __host__ __device__ inline shade_plan plan_shade_tables(scene_dev const& sc, uin
     plan.bytes[kTableTextures] = sc.texture_count * (uint32_t) sizeof(texture_dev);
     plan.bytes[kTableInstances] = sc.instance_count * (uint32_t) sizeof(rt_instance);
     plan.bytes[kTableTransforms] = sc.transform_count * (uint32_t) sizeof(rt_mat4);
+    plan.bytes[kTableNormalMatrices] = sc.transform_count * (uint32_t) sizeof(normal_matrix);
     plan.total = 0;
     for (uint32_t t = 0; t < kTableCount; ++t) {
         uint32_t const padded = (plan.bytes[t] + 15u) & ~15u;

@@ -285,6 +285,26 @@ __global__ void __launch_bounds__(64) primary_ids_kernel(render_params const p) 
     }
 }
 
+// The shader's inverse(mat3(transform)) (megakernel_raytracer.comp:299, :474), once per
+// transform instead of once per hit: the same inverse33 on the same three columns, compiled
+// without contraction like the shading code, so the table holds the bits a hit would compute.
+__global__ void normal_matrix_kernel(const rt_mat4* transforms, uint32_t count,
+    rtd::normal_matrix* out) {
+    uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) {
+        return;
+    }
+    rt_mat4 const& m = transforms[i];
+    rtd::m33 m3;
+    m3.c0 = rtd::mk3(m.m[0][0], m.m[0][1], m.m[0][2]);
+    m3.c1 = rtd::mk3(m.m[1][0], m.m[1][1], m.m[1][2]);
+    m3.c2 = rtd::mk3(m.m[2][0], m.m[2][1], m.m[2][2]);
+    rtd::m33 const inv = rtd::inverse33(m3);
+    out[i].c0 = make_float4(inv.c0.x, inv.c0.y, inv.c0.z, 0.0f);
+    out[i].c1 = make_float4(inv.c1.x, inv.c1.y, inv.c1.z, 0.0f);
+    out[i].c2 = make_float4(inv.c2.x, inv.c2.y, inv.c2.z, 0.0f);
+}
+
 __global__ void clear_rgba_kernel(float4* img, size_t count) {
     size_t const i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
@@ -1648,6 +1668,19 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         d.triangles = r->upload(s.triangles, s.triangle_count);
         d.transforms = r->upload(s.transforms, s.transform_count);
         d.inverse_transforms = r->upload(s.inverse_transforms, s.transform_count);
+        {
+            normal_matrix* table = nullptr;
+            size_t const count = std::max<size_t>(s.transform_count, 1);
+            HIP_CHECK(hipMalloc((void**) &table, count * sizeof(normal_matrix)));
+            r->scene_allocs.push_back(table);
+            if (s.transform_count > 0) {
+                hipLaunchKernelGGL(normal_matrix_kernel, dim3((s.transform_count + 63u) / 64u),
+                    dim3(64), 0, 0, d.transforms, s.transform_count, table);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(nullptr));  // render calls run on other streams
+            }
+            d.normal_matrices = table;
+        }
         d.materials = r->upload(s.materials, s.material_count);
         d.lights = r->upload(s.lights, s.light_count);
         std::vector<texture_dev> textures(s.texture_count);

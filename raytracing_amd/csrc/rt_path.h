@@ -59,6 +59,17 @@ RT_DEV void trace_pair(scene_dev const& sc, fast_stack const& stk, ray_pair cons
 
 RT_DEV f3 load3(const float* p) { return mk3(p[0], p[1], p[2]); }
 
+// inverse(mat3(transform)) of the shader, from the table made at upload (same inverse33, same
+// bits as evaluating it here).
+RT_DEV m33 load_normal_matrix(scene_dev const& sc, int32_t transform) {
+    normal_matrix const n = sc.normal_matrices[transform];
+    m33 m;
+    m.c0 = mk3(n.c0.x, n.c0.y, n.c0.z);
+    m.c1 = mk3(n.c1.x, n.c1.y, n.c1.z);
+    m.c2 = mk3(n.c2.x, n.c2.y, n.c2.z);
+    return m;
+}
+
 // Third phase of closest_hit (megakernel_raytracer.comp:280-322): interpolate
 // the hit, build the tangent frame and move it to world space.
 RT_DEV void fill_hit_state(scene_dev const& sc, hit_result const& hr, f3 origin, f3 direction,
@@ -89,7 +100,7 @@ RT_DEV void fill_hit_state(scene_dev const& sc, hit_result const& hr, f3 origin,
         m3.c0 = mk3(m.m[0][0], m.m[0][1], m.m[0][2]);
         m3.c1 = mk3(m.m[1][0], m.m[1][1], m.m[1][2]);
         m3.c2 = mk3(m.m[2][0], m.m[2][1], m.m[2][2]);
-        st.normal = normalize3(tmul33(inverse33(m3), st.normal));
+        st.normal = normalize3(tmul33(load_normal_matrix(sc, inst.transform), st.normal));
         st.tangent = normalize3(mul33(m3, st.tangent));
         st.bitangent = normalize3(mul33(m3, st.bitangent));
     }
@@ -162,7 +173,7 @@ RT_DEV bool propose_light(scene_dev const& sc, uint32_t& seed, f3 ray_direction,
             m3.c1 = mk3(m.m[1][0], m.m[1][1], m.m[1][2]);
             m3.c2 = mk3(m.m[2][0], m.m[2][1], m.m[2][2]);
             c3 = mk3(m.m[3][0], m.m[3][1], m.m[3][2]);
-            inv3 = inverse33(m3);
+            inv3 = load_normal_matrix(sc, light.transform);
         }
         f3 const light_pos =
             ((m3.c0 * local_pos.x + m3.c1 * local_pos.y) + m3.c2 * local_pos.z) + c3 * 1.0f;

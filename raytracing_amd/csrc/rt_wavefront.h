@@ -834,7 +834,7 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
     if (RT_SHADE_STAGE) {
         shade_plan const plan = plan_shade_tables(p.sc, kShadeLdsBudget);
         const void* const source[kTableCount] = {p.sc.lights, p.sc.materials, p.sc.meshes,
-            p.sc.textures, p.sc.instances, p.sc.transforms};
+            p.sc.textures, p.sc.instances, p.sc.transforms, p.sc.normal_matrices};
         uint32_t* const words = reinterpret_cast<uint32_t*>(shade_lds);
         for (uint32_t t = 0; t < kTableCount; ++t) {
             if (plan.offset[t] == kNotStaged) {
@@ -858,6 +858,8 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
         sc.textures = static_cast<const texture_dev*>(staged(kTableTextures, p.sc.textures));
         sc.instances = static_cast<const rt_instance*>(staged(kTableInstances, p.sc.instances));
         sc.transforms = static_cast<const rt_mat4*>(staged(kTableTransforms, p.sc.transforms));
+        sc.normal_matrices = static_cast<const normal_matrix*>(
+            staged(kTableNormalMatrices, p.sc.normal_matrices));
     }
     const uint32_t* const live = p.live;
     uint32_t total_hits = 0, total_skipped = 0, samples = 0;
