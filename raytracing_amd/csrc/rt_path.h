@@ -87,22 +87,32 @@ RT_DEV void fill_hit_state(scene_dev const& sc, hit_result const& hr, f3 origin,
     // world-space ray against the object-space normal, as in the shader
     st.front_face = dot3(direction, outward) < 0.0f;
     st.normal = st.front_face ? outward : -outward;
-    f3 const dp1 = b - a;
-    f3 const dp2 = c - a;
-    float const du1 = b_pu.w - a_pu.w, dv1 = b_nv.w - a_nv.w;
-    float const du2 = c_pu.w - a_pu.w, dv2 = c_nv.w - a_nv.w;
-    float const inv = 1.0f / (du1 * dv2 - du2 * dv1);
-    st.tangent = (dp1 * dv2 - dp2 * dv1) * inv;
-    st.bitangent = (dp1 * (-du2) + dp2 * du1) * inv;
+    // The tangent frame (:299-314) is read by the normal map alone (get_surface_info, :163-169):
+    // it is built for surfaces that have one - a division, two normalisations and two matrix
+    // products that every other hit went through for nothing.
+    bool const mapped = inst.light < 0 && inst.material >= 0 &&
+                        sc.materials[inst.material].normal_tex >= 0;
+    st.tangent = st.bitangent = splat3(0.0f);
+    if (mapped) {
+        f3 const dp1 = b - a;
+        f3 const dp2 = c - a;
+        float const du1 = b_pu.w - a_pu.w, dv1 = b_nv.w - a_nv.w;
+        float const du2 = c_pu.w - a_pu.w, dv2 = c_nv.w - a_nv.w;
+        float const inv = 1.0f / (du1 * dv2 - du2 * dv1);
+        st.tangent = (dp1 * dv2 - dp2 * dv1) * inv;
+        st.bitangent = (dp1 * (-du2) + dp2 * du1) * inv;
+    }
     if (inst.transform >= 0) {
-        rt_mat4 const& m = sc.transforms[inst.transform];
-        m33 m3;
-        m3.c0 = mk3(m.m[0][0], m.m[0][1], m.m[0][2]);
-        m3.c1 = mk3(m.m[1][0], m.m[1][1], m.m[1][2]);
-        m3.c2 = mk3(m.m[2][0], m.m[2][1], m.m[2][2]);
         st.normal = normalize3(tmul33(load_normal_matrix(sc, inst.transform), st.normal));
-        st.tangent = normalize3(mul33(m3, st.tangent));
-        st.bitangent = normalize3(mul33(m3, st.bitangent));
+        if (mapped) {
+            rt_mat4 const& m = sc.transforms[inst.transform];
+            m33 m3;
+            m3.c0 = mk3(m.m[0][0], m.m[0][1], m.m[0][2]);
+            m3.c1 = mk3(m.m[1][0], m.m[1][1], m.m[1][2]);
+            m3.c2 = mk3(m.m[2][0], m.m[2][1], m.m[2][2]);
+            st.tangent = normalize3(mul33(m3, st.tangent));
+            st.bitangent = normalize3(mul33(m3, st.bitangent));
+        }
     }
     st.u = (hr.b0 * a_pu.w + hr.b1 * b_pu.w) + hr.b2 * c_pu.w;
     st.v = (hr.b0 * a_nv.w + hr.b1 * b_nv.w) + hr.b2 * c_nv.w;

@@ -233,8 +233,9 @@ def write_instanced_scene(directory, grid=100, sphere_segments=128, sphere_rings
 def write_textured_scene(directory, resolution=(160, 120), tile=(40, 30), max_depth=4,
                          with_area_light=True):
     """A checker-textured floor, a rough metal and a glass sphere under an HDR environment map
-    (plus an optional textured area light): exercises albedo / metallic-roughness / emission
-    textures and the environment-map sky path.  Returns the JSON path."""
+    (plus an optional textured area light): exercises albedo / normal / metallic-roughness /
+    emission textures (the normal map on an untransformed and on a rotated, scaled surface) and
+    the environment-map sky path.  Returns the JSON path."""
     os.makedirs(os.path.join(directory, "meshes"), exist_ok=True)
     os.makedirs(os.path.join(directory, "tex"), exist_ok=True)
     write_uv_sphere_obj(os.path.join(directory, "meshes", "sphere.obj"), 24, 12)
@@ -260,6 +261,13 @@ def write_textured_scene(directory, resolution=(160, 120), tile=(40, 30), max_de
     glow[..., 2] = 160
     glow[..., 3] = 255
     write_png(os.path.join(directory, "tex", "glow.png"), glow)
+    by, bx = np.mgrid[0:32, 0:32]
+    bumps = np.zeros((32, 32, 4), dtype=np.uint8)   # a normal map: tilts of up to ~25 degrees
+    bumps[..., 0] = np.round(128 + 55 * np.sin(bx * (2 * np.pi / 8)))
+    bumps[..., 1] = np.round(128 + 55 * np.cos(by * (2 * np.pi / 16)))
+    bumps[..., 2] = 235
+    bumps[..., 3] = 255
+    write_png(os.path.join(directory, "tex", "bumps.png"), bumps)
     h, w = 32, 64
     vv, uu = np.mgrid[0:h, 0:w]
     sky = np.zeros((h, w, 3))
@@ -275,13 +283,14 @@ def write_textured_scene(directory, resolution=(160, 120), tile=(40, 30), max_de
         "sky_light": {"intensity": [1.0, 0.9, 0.8], "environment_tex": "tex/sky.hdr"},
         "material": {
             "floor": {"albedo": [1.0, 1.0, 1.0], "albedo_tex": "tex/checker.png",
-                      "roughness": 0.6},
+                      "normal_tex": "tex/bumps.png", "roughness": 0.6},
             "metal": {"albedo": [0.9, 0.8, 0.6], "metallic": 1.0, "roughness": 0.3,
                       "anisotropic": 0.4, "metallic_roughness_tex": "tex/mr.png"},
             "glass": {"albedo": [1.0, 1.0, 1.0], "spec_trans": 1.0, "ior": 1.45,
                       "roughness": 0.05},
             "coat": {"albedo": [0.1, 0.5, 0.2], "roughness": 0.2, "clearcoat": 1.0,
-                     "clearcoat_gloss": 0.7, "sheen": 0.5, "subsurface": 0.3},
+                     "clearcoat_gloss": 0.7, "sheen": 0.5, "subsurface": 0.3,
+                     "normal_tex": "tex/bumps.png"},
         },
         "primitive": {
             "floor": {"mesh": "meshes/floor.obj", "material": "floor"},

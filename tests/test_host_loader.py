@@ -129,22 +129,23 @@ def test_snapshot_round_trip(tmp_path, textured):
     for name in ("tlas", "blas", "meshes", "instances", "triangles", "transforms",
                  "inverse_transforms", "materials", "lights"):
         assert textured.array(name).tobytes() == again.array(name).tobytes(), name
-    assert again.desc.texture_count == textured.desc.texture_count == 4
-    for i in range(4):
+    assert again.desc.texture_count == textured.desc.texture_count == 6
+    for i in range(6):
         a, b = textured.desc.textures[i], again.desc.textures[i]
         assert (a.width, a.height, a.format) == (b.width, b.height, b.format)
 
 
 def test_texture_decoding_and_sky_luminance_quirk(textured):
     d = textured.desc
-    # load order: materials sorted by key (coat, floor, glass, metal), then lights
-    fmt = [(d.textures[i].width, d.textures[i].height, d.textures[i].format) for i in range(4)]
-    assert fmt == [(64, 64, 0), (32, 32, 0), (16, 16, 0), (64, 32, 1)]
+    # load order: materials sorted by key (coat, floor, glass, metal; a file named by two
+    # materials is loaded twice, as the reference does), then lights
+    fmt = [(d.textures[i].width, d.textures[i].height, d.textures[i].format) for i in range(6)]
+    assert fmt == [(32, 32, 0), (64, 64, 0), (32, 32, 0), (32, 32, 0), (16, 16, 0), (64, 32, 1)]
     import ctypes as C
-    checker = np.frombuffer((C.c_uint8 * (64 * 64 * 4)).from_address(d.textures[0].data),
+    checker = np.frombuffer((C.c_uint8 * (64 * 64 * 4)).from_address(d.textures[1].data),
                             dtype=np.uint8).reshape(64, 64, 4)
     assert tuple(checker[0, 0]) == (40, 60, 200, 255) and tuple(checker[0, 8]) == (240, 210, 80, 255)
-    sky = np.frombuffer((C.c_float * (64 * 32 * 4)).from_address(d.textures[3].data),
+    sky = np.frombuffer((C.c_float * (64 * 32 * 4)).from_address(d.textures[5].data),
                         dtype=np.float32).reshape(32, 64, 4)
     assert (sky[..., 3] == 1.0).all() and sky[..., :3].max() > 20.0
     # total luminance sums floats [i, i+1, i+2] for i = 0, 4, ... < width*height:
