@@ -305,6 +305,16 @@ __global__ void normal_matrix_kernel(const rt_mat4* transforms, uint32_t count,
     out[i].c2 = make_float4(inv.c2.x, inv.c2.y, inv.c2.z, 0.0f);
 }
 
+// Fills the derived fields of the device's material table (derive_material).
+__global__ void derive_materials_kernel(rt_material* materials, uint32_t count) {
+    uint32_t const i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) {
+        rt_material m = materials[i];
+        rtd::derive_material(m);
+        materials[i] = m;
+    }
+}
+
 __global__ void clear_rgba_kernel(float4* img, size_t count) {
     size_t const i = (size_t) blockIdx.x * blockDim.x + threadIdx.x;
     if (i < count) {
@@ -1681,7 +1691,16 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
             }
             d.normal_matrices = table;
         }
-        d.materials = r->upload(s.materials, s.material_count);
+        {
+            rt_material* const table = r->upload(s.materials, s.material_count);
+            if (s.material_count > 0) {
+                hipLaunchKernelGGL(derive_materials_kernel, dim3((s.material_count + 63u) / 64u),
+                    dim3(64), 0, 0, table, s.material_count);
+                HIP_CHECK(hipGetLastError());
+                HIP_CHECK(hipStreamSynchronize(nullptr));
+            }
+            d.materials = table;
+        }
         d.lights = r->upload(s.lights, s.light_count);
         std::vector<texture_dev> textures(s.texture_count);
         for (uint32_t i = 0; i < s.texture_count; ++i) {

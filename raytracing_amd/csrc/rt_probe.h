@@ -66,7 +66,9 @@ __global__ void __launch_bounds__(64) probe_kernel(scene_dev const sc, uint32_t 
     case RT_HIP_PROBE_SAMPLE_DISNEY: {  // disney.glsl:250-315
         // the surface of megakernel_raytracer.comp:126-182 for a hit on this material alone
         scene_dev one = sc;
-        one.materials = &q.material;
+        rt_material material = q.material;
+        derive_material(material);  // as the upload does for the scene's table
+        one.materials = &material;
         hit_state st{};
         st.normal = mk3(q.f[0], q.f[1], q.f[2]);
         st.tangent = st.bitangent = st.position = splat3(0.0f);

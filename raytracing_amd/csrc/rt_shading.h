@@ -18,7 +18,7 @@ struct hit_state {
 // shaders/raytracer/state.glsl:18-35
 struct surface {
     f3 albedo, emission;
-    float metallic, spec_trans, eta, ior, subsurface, roughness, specular_tint;
+    float metallic, spec_trans, eta, ior, inv_ior, subsurface, roughness, specular_tint;
     float ax, ay, sheen, sheen_tint, clearcoat, clearcoat_gloss;
 };
 
@@ -91,6 +91,21 @@ RT_DEV f3 texture_rgb(scene_dev const& sc, int tex, float u, float v) {
 }
 
 // ---------------------------------------------------------------------------
+// What get_surface_info (:145, :178-180) and eval_disney (disney.glsl:214) compute from the
+// material alone, hit after hit: 1 / ior and the anisotropic roughness pair.  The device copy
+// of the material table carries them in the record's padding, filled once per upload by
+// derive_material - the same operations on the same inputs, so the same bits.
+RT_DEV void derive_material(rt_material& m) {
+    m._p0[0] = 1.0f / m.ior;
+    float const aspect = sqrtf(1.0f - m.anisotropic * 0.9f);
+    m._p0[1] = fmaxf(0.001f, m.roughness / aspect);
+    m._p0[2] = fmaxf(0.001f, m.roughness * aspect);
+}
+RT_DEV float material_inv_ior(rt_material const& m) { return m._p0[0]; }
+RT_DEV float material_ax(rt_material const& m) { return m._p0[1]; }
+RT_DEV float material_ay(rt_material const& m) { return m._p0[2]; }
+
+// ---------------------------------------------------------------------------
 // shaders/raytracer/megakernel_raytracer.comp:126-182 (get_surface_info).
 // May replace st.normal with the normal-mapped one.
 RT_DEV void make_surface(scene_dev const& sc, hit_state& st, surface& si) {
@@ -109,8 +124,9 @@ RT_DEV void make_surface(scene_dev const& sc, hit_state& st, surface& si) {
         si.emission = mk3(m.emission[0], m.emission[1], m.emission[2]);
         si.metallic = m.metallic;
         si.spec_trans = m.spec_trans;
-        si.eta = st.front_face ? 1.0f / m.ior : m.ior;
+        si.eta = st.front_face ? material_inv_ior(m) : m.ior;
         si.ior = m.ior;
+        si.inv_ior = material_inv_ior(m);
         si.subsurface = m.subsurface;
         si.roughness = m.roughness;
         si.specular_tint = m.specular_tint;
@@ -134,10 +150,10 @@ RT_DEV void make_surface(scene_dev const& sc, hit_state& st, surface& si) {
             si.metallic = texel.z;  // .bg swizzle: blue = metallic, green = roughness
             si.roughness = fmaxf(texel.y * texel.y, 0.001f);
         }
-        // The anisotropy split uses the material's roughness, not the textured one.
-        float const aspect = sqrtf(1.0f - m.anisotropic * 0.9f);
-        si.ax = fmaxf(0.001f, m.roughness / aspect);
-        si.ay = fmaxf(0.001f, m.roughness * aspect);
+        // The anisotropy split uses the material's roughness, not the textured one: it is a
+        // constant of the material (derive_material).
+        si.ax = material_ax(m);
+        si.ay = material_ay(m);
     }
 }
 
@@ -374,7 +390,7 @@ RT_DEV f4 eval_disney(hit_state const& st, surface const& si, lobe_mix const& lm
     float const refl_pdf = g1 * d_ggx / (4.0f * v.z);
 
     if (lm.dielectric_pr > 0.0f && reflect && l.z > 0.0f) {
-        float const fr = (dielectric_fresnel(abs_v_h, 1.0f / si.ior) - lm.f0) / (1.0f - lm.f0);
+        float const fr = (dielectric_fresnel(abs_v_h, si.inv_ior) - lm.f0) / (1.0f - lm.f0);
         f3 const fc = mix3(lm.cspec0, splat3(1.0f), fr);
         f3 const contrib = mk3(fc.x * d_ggx * g2 / refl_denom, fc.y * d_ggx * g2 / refl_denom,
             fc.z * d_ggx * g2 / refl_denom);
