@@ -807,7 +807,7 @@ void settle_binning(rt_hip_renderer& r) {
 }
 
 // Settles an outstanding probe if its events have completed (never waits).
-void settle_binning_probe(rt_hip_renderer& r) {
+void settle_probe(rt_hip_renderer& r) {
     if (!r.probe_pending || hipEventQuery(r.probe_done) != hipSuccess) {
         return;
     }
@@ -999,7 +999,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         (uint32_t) std::min<size_t>(p.pass_count, std::max<size_t>(1, limit / per_pass));
     uint32_t const trips = p.max_depth + 1u;
     if (!fixed) {
-        settle_binning_probe(r);
+        settle_probe(r);
     }
     bool const binned = !fixed && r.binning == RT_HIP_BINNING_ON;
     // trips beyond those measured (a forced ON has measured none) are binned
@@ -2271,7 +2271,7 @@ int rt_hip_ray_binning(rt_hip_renderer* r, uint32_t* state, double* probe_ns_per
             throw std::runtime_error("ray_binning: null argument");
         }
         device_scope const on_device(r->device);
-        settle_binning_probe(*r);
+        settle_probe(*r);
         *state = r->binning;
         *probe_ns_per_ray = r->probe_ns_per_ray;
     });
@@ -2288,7 +2288,7 @@ int rt_hip_trace_refill(rt_hip_renderer* r, uint32_t* state, double* ms_off, dou
             throw std::runtime_error("trace_refill: null argument");
         }
         device_scope const on_device(r->device);
-        settle_binning_probe(*r);
+        settle_probe(*r);
         *state = r->refill;
         if (ms_off) {
             *ms_off = r->refill_ms[0];
