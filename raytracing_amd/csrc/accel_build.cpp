@@ -642,6 +642,46 @@ box3 world_box(rt_scene_desc const& sc, rt_instance const& inst, box3 const& ob)
     return wb;
 }
 
+// A second bound on an instance's world box: the box of its mesh's bounding sphere (centre c,
+// radius r in object space) under the transform, c_world +- r |row_i of the 3x3|.  The box of
+// the eight transformed corners of a rotated object-space box is up to sqrt(3) times too wide
+// per axis (a rotated sphere's most of all); both bounds hold, so their intersection does.
+struct ball {
+    double c[3] = {0.0, 0.0, 0.0};
+    double r = 0.0;
+};
+
+box3 world_ball_box(rt_scene_desc const& sc, rt_instance const& inst, ball const& b) {
+    double centre[3] = {b.c[0], b.c[1], b.c[2]};
+    double reach[3] = {b.r, b.r, b.r};
+    if (inst.transform >= 0) {
+        rt_mat4 const& m = sc.transforms[inst.transform];
+        for (int r = 0; r < 3; ++r) {
+            centre[r] = (double) m.m[0][r] * b.c[0] + (double) m.m[1][r] * b.c[1] +
+                        (double) m.m[2][r] * b.c[2] + (double) m.m[3][r];
+            reach[r] = b.r * std::sqrt((double) m.m[0][r] * m.m[0][r] + (double) m.m[1][r] * m.m[1][r] +
+                                       (double) m.m[2][r] * m.m[2][r]);
+        }
+    }
+    box3 wb;
+    for (int a = 0; a < 3; ++a) {
+        double const lo = centre[a] - reach[a], hi = centre[a] + reach[a];
+        double const pad = 1e-5 * (hi - lo) + 4e-7 * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30;
+        wb.lo[a] = std::nextafter((float) (lo - pad), -std::numeric_limits<float>::infinity());
+        wb.hi[a] = std::nextafter((float) (hi + pad), std::numeric_limits<float>::infinity());
+    }
+    return wb;
+}
+
+box3 intersection(box3 const& a, box3 const& b) {
+    box3 both;
+    for (int k = 0; k < 3; ++k) {
+        both.lo[k] = std::max(a.lo[k], b.lo[k]);
+        both.hi[k] = std::min(a.hi[k], b.hi[k]);
+    }
+    return both;
+}
+
 uint32_t ceil_log2(uint32_t v) {
     uint32_t bits = 0;
     while ((1u << bits) < v) {
@@ -693,6 +733,7 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entrie
 
     // Object-space bounds of every mesh.
     std::vector<box3> mesh_bounds(sc.mesh_count);
+    std::vector<ball> mesh_balls(sc.mesh_count);
     for (uint32_t m = 0; m < sc.mesh_count; ++m) {
         rt_mesh const& mesh = sc.meshes[m];
         if (mesh.triangle_count == 0 ||
@@ -705,6 +746,23 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entrie
             mesh_bounds[m].grow(tri.b.position_texu);
             mesh_bounds[m].grow(tri.c.position_texu);
         }
+        // bounding sphere around the middle of the box
+        ball& b = mesh_balls[m];
+        for (int k = 0; k < 3; ++k) {
+            b.c[k] = 0.5 * ((double) mesh_bounds[m].lo[k] + (double) mesh_bounds[m].hi[k]);
+        }
+        double far2 = 0.0;
+        for (uint32_t t = 0; t < mesh.triangle_count; ++t) {
+            rt_triangle const& tri = sc.triangles[mesh.triangle_offset + t];
+            for (const float* v : {tri.a.position_texu, tri.b.position_texu, tri.c.position_texu}) {
+                double d2 = 0.0;
+                for (int k = 0; k < 3; ++k) {
+                    d2 += ((double) v[k] - b.c[k]) * ((double) v[k] - b.c[k]);
+                }
+                far2 = std::max(far2, d2);
+            }
+        }
+        b.r = std::sqrt(far2) * (1.0 + 1e-12);
     }
     for (uint32_t i = 0; i < sc.instance_count; ++i) {
         rt_instance const& inst = sc.instances[i];
@@ -721,7 +779,9 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entrie
     float const overlap_needed = gate ? (float) atof(gate) : kOpenOverlap;
     std::vector<box3> instance_world(sc.instance_count);
     for (uint32_t i = 0; i < sc.instance_count; ++i) {
-        instance_world[i] = world_box(sc, sc.instances[i], mesh_bounds[sc.instances[i].mesh]);
+        instance_world[i] =
+            intersection(world_box(sc, sc.instances[i], mesh_bounds[sc.instances[i].mesh]),
+                world_ball_box(sc, sc.instances[i], mesh_balls[sc.instances[i].mesh]));
     }
     std::vector<char> crowded(sc.instance_count, 0);
     uint64_t crowded_triangles = 0;
@@ -856,12 +916,15 @@ built_accel build_wide_accel(rt_scene_desc const& sc, uint32_t max_opened_entrie
         // the first half takes the opened entry's place, the second is appended
         entries[at].subtree = node.child0;
         entries[at].object_box = node.b0;
-        entries[at].world = world_box(sc, sc.instances[opened.instance], node.b0);
+        // (a part of the instance: inside the instance's own world box, too)
+        entries[at].world = intersection(
+            world_box(sc, sc.instances[opened.instance], node.b0), instance_world[opened.instance]);
         offer(at);
         tlas_entry second = opened;
         second.subtree = node.child1;
         second.object_box = node.b1;
-        second.world = world_box(sc, sc.instances[opened.instance], node.b1);
+        second.world = intersection(
+            world_box(sc, sc.instances[opened.instance], node.b1), instance_world[opened.instance]);
         entries.push_back(second);
         offer((uint32_t) entries.size() - 1u);
     }
