@@ -24,6 +24,10 @@
 
 using namespace rtd;
 
+#ifndef RT_EXP_F
+#define RT_EXP_F kShadeAll
+#endif
+
 // ---------------------------------------------------------------------------
 // kernels
 
@@ -437,6 +441,7 @@ struct rt_hip_renderer {
     size_t wf_paths = 0;
     uint32_t wf_trips = 0;
     uint32_t wf_extend_grid = 0, wf_extend_waves = 0, wf_shade_grid = 0;  // workgroups, waves
+    uint32_t wf_settle_grid = 0;
     uint32_t wf_finish_grid = 0;
     uint32_t wf_stat_waves = 0;       // slots of wf.wave_stats
     int handover_setting = -1;        // RT_HIP_HANDOVER_BELOW at creation (tuning knob), -1 = default
@@ -904,6 +909,7 @@ void init_launch_plan(rt_hip_renderer& r) {
     // two workgroups of four waves per CU (the kernel's registers allow two waves per
     // SIMD), each with its own LDS copy of the scene's small tables
     r.wf_shade_grid = cus * kShadeGroupsPerCu;
+    r.wf_settle_grid = cus * kSettleGroupsPerCu;
     r.wf_finish_grid = cus * 8u;  // one-wave workgroups, two per SIMD
     r.wf_bin_groups = cus;
     HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(wf_bin_count_kernel),
@@ -912,7 +918,7 @@ void init_launch_plan(rt_hip_renderer& r) {
         hipFuncAttributeMaxDynamicSharedMemorySize, (int) (kBinCount * 4u)));
     // per-wave work counters: they outlive every regrowth of the state arrays
     r.wf_stat_waves = std::max({r.wf_extend_waves, r.wf_shade_grid * (kShadeThreads / 64u),
-        r.wf_finish_grid});
+        r.wf_settle_grid * (kSettleThreads / 64u), r.wf_finish_grid});
     size_t const stat_bytes = (size_t) r.wf_stat_waves * kStatWords * sizeof(unsigned long long);
     HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
     HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
@@ -961,6 +967,8 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
     w.q_closest = (uint32_t*) alloc(paths * 4);
     w.q_shadow = (uint32_t*) alloc(paths * 4);
     w.raw = (uint32_t*) alloc(paths * 4);
+    w.going = (uint2*) alloc(paths * 8);
+    w.going_count = (uint32_t*) alloc(((paths + kRegionSlots - 1u) / kRegionSlots) * 4);
     size_t const chunks = (paths + 63u) / 64u;
     w.chunk_counts = (uint32_t*) alloc(chunks * 4);
     w.tile_sums = (uint32_t*) alloc(((chunks + kTileChunks - 1u) / kTileChunks) * 12);
@@ -1089,6 +1097,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     w.y1 = p.y1;
     w.blocks_x = blocks_x;
     w.block_count = blocks_x * blocks_y;
+    w.padded = ((p.x1 - p.x0) % 8u != 0u || (p.y1 - p.y0) % 8u != 0u) ? 1u : 0u;
     w.tile_width = p.tile_width;
     w.tile_height = p.tile_height;
     w.tiles_x = p.tiles_x;
@@ -1202,8 +1211,12 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                 finish(trip, chunk_bound);  // a no-op unless the compaction handed over
             }
             // a trip has at most one closest-hit and one occlusion ray per path
+            uint32_t const region_bound =
+                (uint32_t) ((paths + kRegionSlots - 1u) / kRegionSlots);  // regions of the live list
+            dim3 const settle_grid(std::min(r.wf_settle_grid,
+                (region_bound + kSettleThreads / 64u - 1u) / (kSettleThreads / 64u)));
             dim3 const shade_grid(std::min(r.wf_shade_grid,
-                (chunk_bound + kShadeThreads / 64u - 1u) / (kShadeThreads / 64u)));
+                (region_bound + kShadeThreads / 64u - 1u) / (kShadeThreads / 64u)));
             rt_hip_renderer::timed_launch t{};
             if (each) {
                 t = r.begin_timing(stream, RT_HIP_KERNEL_EXTEND);
@@ -1232,10 +1245,14 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                 t = r.begin_timing(stream, RT_HIP_KERNEL_SHADE);
             }
             if (trip == 0u) {
-                hipLaunchKernelGGL(wf_shade_kernel<true>, shade_grid, dim3(kShadeThreads),
+                hipLaunchKernelGGL((wf_settle_kernel<true, RT_EXP_F>), settle_grid,
+                    dim3(kSettleThreads), shade_lds, stream, w, trip);
+                hipLaunchKernelGGL((wf_shade_kernel<true, RT_EXP_F>), shade_grid, dim3(kShadeThreads),
                     shade_lds, stream, w, trip);
             } else {
-                hipLaunchKernelGGL(wf_shade_kernel<false>, shade_grid, dim3(kShadeThreads),
+                hipLaunchKernelGGL((wf_settle_kernel<false, RT_EXP_F>), settle_grid,
+                    dim3(kSettleThreads), shade_lds, stream, w, trip);
+                hipLaunchKernelGGL((wf_shade_kernel<false, RT_EXP_F>), shade_grid, dim3(kShadeThreads),
                     shade_lds, stream, w, trip);
             }
             HIP_CHECK(hipGetLastError());
@@ -1307,8 +1324,11 @@ constexpr size_t kScratchChunkCounts = scratch_align(kNoAllocChunks * 4u);
 constexpr size_t kScratchTileSums =
     scratch_align(((kNoAllocChunks + kTileChunks - 1u) / kTileChunks) * 12u);
 constexpr size_t kScratchControl = scratch_align((size_t) (kNoAllocTrips + 1u) * kCtlWords * 4u);
-constexpr size_t kScratchBytes = 8u * kScratchVec4 + kScratchVec2 + 5u * kScratchWord +
-                                 kScratchChunkCounts + kScratchTileSums + kScratchControl;
+constexpr size_t kScratchGoingCount =
+    scratch_align(((kNoAllocPaths + kRegionSlots - 1u) / kRegionSlots) * 4u);
+constexpr size_t kScratchBytes = 8u * kScratchVec4 + 2u * kScratchVec2 + 5u * kScratchWord +
+                                 kScratchGoingCount + kScratchChunkCounts + kScratchTileSums +
+                                 kScratchControl;
 static_assert(kScratchBytes <= (size_t) 48u << 20, "keep the resident scratch array modest");
 
 static __device__ __align__(256) unsigned char scratch[kScratchBytes];
@@ -1357,6 +1377,8 @@ wavefront_params carve_scratch(unsigned char* base, unsigned long long* wave_sta
     w.q_closest = (uint32_t*) take(kScratchWord);
     w.q_shadow = (uint32_t*) take(kScratchWord);
     w.raw = (uint32_t*) take(kScratchWord);
+    w.going = (uint2*) take(kScratchVec2);
+    w.going_count = (uint32_t*) take(kScratchGoingCount);
     w.chunk_counts = (uint32_t*) take(kScratchChunkCounts);
     w.tile_sums = (uint32_t*) take(kScratchTileSums);
     w.control = (uint32_t*) take(kScratchControl);
@@ -2317,6 +2339,25 @@ int rt_hip_destroy(rt_hip_renderer* r) {
         }
         device_scope const on_device(r->device);
         (void) hipDeviceSynchronize();
+#ifdef RT_SHADE_REGION_TIMING
+        {
+            unsigned long long host[2][12] = {};
+            (void) hipMemcpyFromSymbol(host, HIP_SYMBOL(g_region_cycles), sizeof(host));
+            for (int f = 0; f < 2; ++f) {
+                unsigned long long sum = 0;
+                for (int k = 0; k < 12; ++k) {
+                    sum += host[f][k];
+                }
+                fprintf(stderr, "shade regions %s:", f == 0 ? "trip 0" : "later trips");
+                for (int k = 0; k < 12; ++k) {
+                    fprintf(stderr, " [%d] %.1f%%", k, sum ? 100.0 * (double) host[f][k] / (double) sum : 0.0);
+                }
+                fprintf(stderr, "  total %.3g cycles\n", (double) sum);
+            }
+            unsigned long long const zero[2][12] = {};
+            (void) hipMemcpyToSymbol(HIP_SYMBOL(g_region_cycles), zero, sizeof(zero));
+        }
+#endif
         r->free_scene();
         r->free_wavefront();
         (void) hipFree(r->wf.wave_stats);

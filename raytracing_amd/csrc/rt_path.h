@@ -72,6 +72,7 @@ RT_DEV m33 load_normal_matrix(scene_dev const& sc, int32_t transform) {
 
 // Third phase of closest_hit (megakernel_raytracer.comp:280-322): interpolate
 // the hit, build the tangent frame and move it to world space.
+template <uint32_t F = kShadeAll>
 RT_DEV void fill_hit_state(scene_dev const& sc, hit_result const& hr, f3 origin, f3 direction,
     hit_state& st) {
     rt_instance const inst = sc.instances[hr.instance];
@@ -90,7 +91,7 @@ RT_DEV void fill_hit_state(scene_dev const& sc, hit_result const& hr, f3 origin,
     // The tangent frame (:299-314) is read by the normal map alone (get_surface_info, :163-169):
     // it is built for surfaces that have one - a division, two normalisations and two matrix
     // products that every other hit went through for nothing.
-    bool const mapped = inst.light < 0 && inst.material >= 0 &&
+    bool const mapped = feat<F>(kFeatTextures) && inst.light < 0 && inst.material >= 0 &&
                         sc.materials[inst.material].normal_tex >= 0;
     st.tangent = st.bitangent = splat3(0.0f);
     if (mapped) {
@@ -135,18 +136,20 @@ struct light_sample {
 // sample when it is blocked.  None of the work after the shadow ray in the
 // shader draws random numbers, so hoisting it keeps the random sequence.
 // Returns false when the shader returns false before tracing anything.
+template <uint32_t F = kShadeAll>
 RT_DEV bool propose_light(scene_dev const& sc, uint32_t& seed, f3 ray_direction, f3 position,
     light_sample& ls) {
     float const light_pdf = 1.0f / (float) sc.light_count;
     rt_light const light = sc.lights[rand_uint(seed, 0u, sc.light_count - 1u)];
     ls.type = light.type;
-    if (light.type == RT_LIGHT_SKY) {
+    if (feat<F>(kFeatSky) && light.type == RT_LIGHT_SKY) {
         // hemisphere around the incoming ray direction (not the normal), as in the shader;
         // with the opt-in tables, a direction drawn in proportion to the map instead
-        bool const importance = sc.sky_density != nullptr && light.emission_tex >= 0;
+        bool const importance =
+            feat<F>(kFeatTextures) && sc.sky_density != nullptr && light.emission_tex >= 0;
         f3 const direction = importance ? sample_sky_importance(sc, seed)
                                         : uniform_sample_hemisphere(seed, ray_direction);
-        f4 const ip = eval_sky_light(sc, direction);
+        f4 const ip = eval_sky_light<F>(sc, direction);
         if (importance && !(ip.w > 0.0f)) {
             return false;  // a pole of the map: zero density, nothing to weigh
         }
@@ -196,7 +199,7 @@ RT_DEV bool propose_light(scene_dev const& sc, uint32_t& seed, f3 ray_direction,
         float const dist2 = dist * dist;
         f3 const direction = light_to_frag / dist;
         f3 intensity = mk3(light.intensity[0], light.intensity[1], light.intensity[2]);
-        if (light.emission_tex >= 0) {
+        if (feat<F>(kFeatTextures) && light.emission_tex >= 0) {
             float const u = (bc.x * a_pu.w + bc.y * b_pu.w) + bc.z * c_pu.w;
             float const v = (bc.x * a_nv.w + bc.y * b_nv.w) + bc.z * c_nv.w;
             intensity = intensity * texture_rgb(sc, light.emission_tex, u, v);
@@ -210,6 +213,37 @@ RT_DEV bool propose_light(scene_dev const& sc, uint32_t& seed, f3 ray_direction,
     }
     return false;  // distant lights: the shader's branch is empty
 }
+
+// Diagnostic builds (RT_SHADE_REGION_TIMING): cycles a wave spends in each part of shade_trip.
+struct region_clock {
+#ifdef RT_SHADE_REGION_TIMING
+    unsigned long long cycles[12] = {};
+    unsigned long long last = 0;
+    RT_DEV void start() {
+        __builtin_amdgcn_sched_barrier(0);
+        last = __builtin_readcyclecounter();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    RT_DEV void mark(int region) {
+        __builtin_amdgcn_sched_barrier(0);
+        unsigned long long const now = __builtin_readcyclecounter();
+        cycles[region] += now - last;
+        last = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#else
+    RT_DEV void start() {}
+    RT_DEV void mark(int) {}
+#endif
+};
+
+// What shade_trip calls once a going path's last load has been issued (the light's triangle):
+// from there to the end of the trip - BSDF sampling and the two evaluations, more than half of
+// its instructions - nothing waits for memory, so a caller can start the loads of its NEXT path
+// there and find them complete when it gets to it.
+struct no_prefetch {
+    RT_DEV void after_loads() {}
+};
 
 // What a path carries from one bounce to the next.
 struct path_state {
@@ -231,43 +265,56 @@ struct path_state {
 // those of the shader; only the surface state no longer has to stay alive across a
 // traversal.  On return `rp` describes the next trip's rays; the path is over when it has
 // neither.
+template <uint32_t F = kShadeAll, int PART = kTripWhole, class HOOK = no_prefetch>
 RT_DEV void shade_trip(scene_dev const& sc, uint32_t max_depth, ray_pair& rp,
-    pair_result const& pr, path_state& ps, uint32_t& closest_hits, uint32_t& shadow_skipped) {
+    pair_result const& pr, path_state& ps, uint32_t& closest_hits, uint32_t& shadow_skipped,
+    region_clock& rc, HOOK& hook) {
     if (rp.has_shadow && !pr.occluded) {
         ps.radiance = ps.radiance + ps.nee;  // :547-549
     }
     rp.has_shadow = false;
     if (rp.has_closest) {
         rp.has_closest = false;  // set again below when the path goes on
-        if (!pr.hit) {
+        if (PART != kTripGoesOn && !pr.hit) {
             // :518-527
-            f4 const ip = eval_sky_light(sc, rp.direction);
+            f4 const ip = eval_sky_light<F>(sc, rp.direction);
             if (ip.w > 0.0f) {
                 float const mis = ps.depth > 0u ? power_heuristic(ps.last_bsdf_pdf, ip.w) : 1.0f;
                 ps.radiance = ps.radiance + (mk3(ip.x, ip.y, ip.z) * mis) * ps.throughput;
             }
+            rc.mark(1);
         } else {
             ++closest_hits;
             hit_state st;
-            fill_hit_state(sc, pr.best, rp.origin, rp.direction, st);
+            fill_hit_state<F>(sc, pr.best, rp.origin, rp.direction, st);
+            rc.mark(2);
             surface si;
-            make_surface(sc, st, si);
+            make_surface<F, PART>(sc, st, si);
             ps.radiance = ps.radiance + si.emission * ps.throughput;
-            if (st.light < 0 && ps.depth != max_depth) {
+            rc.mark(3);
+            bool const goes_on = PART == kTripGoesOn
+                                     ? true
+                                     : (PART == kTripEnds ? false
+                                                          : st.light < 0 && ps.depth != max_depth);
+            if (goes_on) {
                 lobe_mix const lm = make_lobe_mix(st, si, rp.direction);
+                rc.mark(4);
                 // state.glsl:14-16 - undoes the ray-facing flip, so the offset follows the
                 // mesh's own normal direction even for back-face hits
                 f3 const front_face_normal = st.front_face ? st.normal : -st.normal;
                 f3 const shadow_origin = st.position + front_face_normal * kEpsilon;
                 light_sample ls;
                 bool const have_light =
-                    propose_light(sc, ps.seed, rp.direction, shadow_origin, ls);
-                f3 const next_direction = sample_disney(ps.seed, st, si, lm);
+                    propose_light<F>(sc, ps.seed, rp.direction, shadow_origin, ls);
+                rc.mark(5);
+                hook.after_loads();
+                f3 const next_direction = sample_disney<F>(ps.seed, st, si, lm);
+                rc.mark(6);
                 // One eval_disney body serves both uses (:541-550 and :554-560).
 #pragma nounroll
                 for (int k = have_light ? 0 : 1; k < 2; ++k) {
                     f3 const l = k == 0 ? ls.wi : next_direction;
-                    f4 const bsdf = eval_disney(st, si, lm, l);
+                    f4 const bsdf = eval_disney<F>(st, si, lm, l);
                     if (k == 0) {
                         if (bsdf.w > 0.0f) {
                             bool const is_delta = ls.type == RT_LIGHT_DISTANT;
@@ -292,12 +339,21 @@ RT_DEV void shade_trip(scene_dev const& sc, uint32_t max_depth, ray_pair& rp,
                         }
                     }
                 }
+                rc.mark(7);
                 rp.direction = next_direction;
                 rp.origin = st.position + next_direction * kEpsilon;
                 ++ps.depth;
             }
         }
     }
+}
+
+template <uint32_t F = kShadeAll, int PART = kTripWhole>
+RT_DEV void shade_trip(scene_dev const& sc, uint32_t max_depth, ray_pair& rp,
+    pair_result const& pr, path_state& ps, uint32_t& closest_hits, uint32_t& shadow_skipped) {
+    region_clock rc;
+    no_prefetch hook;
+    shade_trip<F, PART>(sc, max_depth, rp, pr, ps, closest_hits, shadow_skipped, rc, hook);
 }
 
 // Seeds a pixel for one pass and builds its jittered primary ray

@@ -23,6 +23,31 @@ struct surface {
 };
 
 // ---------------------------------------------------------------------------
+// What the uploaded scene's materials and lights can make the shading code do.  The shading
+// kernel of the pipeline is compiled once per supported combination (wf_shade_kernel) and the
+// upload picks the smallest one that covers the scene: a branch that no material or light of the
+// scene can take is left out at compile time, which frees its registers and cannot change a
+// bit of any result.  kShadeAll keeps everything (the fused kernels, the probes).
+enum : uint32_t {
+    kFeatGlass = 1u,      // some material has spec_trans != 0 (the glass lobe can get a weight)
+    kFeatClearcoat = 2u,  // some material has clearcoat != 0
+    kFeatMetal = 4u,      // some material has metallic != 0 or a metallic-roughness texture
+    kFeatTextures = 8u,   // some material or light (the sky included) names a texture
+    kFeatSky = 16u,       // there is a sky light
+    kShadeAll = 31u,
+};
+template <uint32_t F>
+RT_DEV constexpr bool feat(uint32_t bit) { return (F & bit) != 0u; }
+
+// Which paths a caller of shade_trip hands it (the pipeline sorts them beforehand, so each of
+// its two shading kernels carries only the code its paths can reach).
+enum : int {
+    kTripWhole = 0,   // any path
+    kTripEnds = 1,    // only paths that end at this trip: no ray, a miss, a light, or max_depth
+    kTripGoesOn = 2,  // only paths whose ray hit a surface below max_depth
+};
+
+// ---------------------------------------------------------------------------
 // texture(): bilinear, REPEAT addressing, one mip level, fp32 weights, texel
 // centres at +0.5 (sampler: src/vulkan/vulkan_image.cpp:309-330).
 RT_DEV uint32_t wrap_repeat(int i, uint32_t size) {
@@ -108,13 +133,15 @@ RT_DEV float material_ay(rt_material const& m) { return m._p0[2]; }
 // ---------------------------------------------------------------------------
 // shaders/raytracer/megakernel_raytracer.comp:126-182 (get_surface_info).
 // May replace st.normal with the normal-mapped one.
+template <uint32_t F = kShadeAll, int PART = kTripWhole>
 RT_DEV void make_surface(scene_dev const& sc, hit_state& st, surface& si) {
+    constexpr bool kTex = feat<F>(kFeatTextures);
     si = surface{};
-    if (st.light >= 0) {
+    if (PART != kTripGoesOn && st.light >= 0) {
         rt_light const& light = sc.lights[st.light];
         if (st.front_face || light.type == RT_LIGHT_AREA_DOUBLE_SIDED) {
             si.emission = mk3(light.intensity[0], light.intensity[1], light.intensity[2]);
-            if (light.emission_tex >= 0) {
+            if (kTex && light.emission_tex >= 0) {
                 si.emission = si.emission * texture_rgb(sc, light.emission_tex, st.u, st.v);
             }
         }
@@ -134,18 +161,18 @@ RT_DEV void make_surface(scene_dev const& sc, hit_state& st, surface& si) {
         si.sheen_tint = m.sheen_tint;
         si.clearcoat = m.clearcoat;
         si.clearcoat_gloss = m.clearcoat_gloss;
-        if (m.albedo_tex >= 0) {
+        if (kTex && m.albedo_tex >= 0) {
             si.albedo = si.albedo * texture_rgb(sc, m.albedo_tex, st.u, st.v);
         }
-        if (m.emission_tex >= 0) {
+        if (kTex && m.emission_tex >= 0) {
             si.emission = si.emission * texture_rgb(sc, m.emission_tex, st.u, st.v);
         }
-        if (m.normal_tex >= 0) {
+        if (kTex && m.normal_tex >= 0) {
             f3 const texel = texture_rgb(sc, m.normal_tex, st.u, st.v);
             f3 const n = normalize3(texel * 2.0f - splat3(1.0f));
             st.normal = normalize3((st.tangent * n.x + st.bitangent * n.y) + st.normal * n.z);
         }
-        if (m.metallic_roughness_tex >= 0) {
+        if (kTex && m.metallic_roughness_tex >= 0) {
             f4 const texel = sample_texture(sc, m.metallic_roughness_tex, st.u, st.v);
             si.metallic = texel.z;  // .bg swizzle: blue = metallic, green = roughness
             si.roughness = fmaxf(texel.y * texel.y, 0.001f);
@@ -345,7 +372,11 @@ struct lobe_term {
 };
 
 // eval_disney, :170-248.  l_world: direction leaving the surface.  Returns (f*|cos|, pdf).
+template <uint32_t F = kShadeAll>
 RT_DEV f4 eval_disney(hit_state const& st, surface const& si, lobe_mix const& lm, f3 l_world) {
+    constexpr bool kGlass = feat<F>(kFeatGlass);
+    constexpr bool kMetal = feat<F>(kFeatMetal);
+    constexpr bool kClearcoat = feat<F>(kFeatClearcoat);
     f3 const v = lm.v;
     f3 const l = mk3(dot3(l_world, lm.t), dot3(l_world, lm.b), dot3(l_world, st.normal));
     f3 h = l.z > 0.0f ? normalize3(l + v) : normalize3(l + v * si.eta);
@@ -379,9 +410,10 @@ RT_DEV f4 eval_disney(hit_state const& st, surface const& si, lobe_mix const& lm
     // The three reflection lobes share D, G1, G2 (:95-110); they differ in the Fresnel colour.
     bool const want_reflection =
         reflect && l.z > 0.0f &&
-        (lm.dielectric_pr > 0.0f || lm.metal_pr > 0.0f || lm.glass_pr > 0.0f);
+        (lm.dielectric_pr > 0.0f || (kMetal && lm.metal_pr > 0.0f) ||
+            (kGlass && lm.glass_pr > 0.0f));
     float d_ggx = 0.0f, g1 = 0.0f, g2 = 0.0f;
-    if (want_reflection || (lm.glass_pr > 0.0f && !reflect && l.z < 0.0f)) {
+    if (want_reflection || (kGlass && lm.glass_pr > 0.0f && !reflect && l.z < 0.0f)) {
         d_ggx = gtr2_aniso(h.z, h.x, h.y, si.ax, si.ay);
         g1 = smith_g_aniso(fabsf(v.z), v.x, v.y, si.ax, si.ay);
         g2 = g1 * smith_g_aniso(fabsf(l.z), l.x, l.y, si.ax, si.ay);
@@ -397,14 +429,14 @@ RT_DEV f4 eval_disney(hit_state const& st, surface const& si, lobe_mix const& lm
         f = f + contrib * lm.dielectric_wt;
         pdf += lm.dielectric_pr * refl_pdf;
     }
-    if (lm.metal_pr > 0.0f && reflect && l.z > 0.0f) {
+    if (kMetal && lm.metal_pr > 0.0f && reflect && l.z > 0.0f) {
         f3 const fc = mix3(si.albedo, splat3(1.0f), schlick_weight(abs_v_h));
         f3 const contrib = mk3(fc.x * d_ggx * g2 / refl_denom, fc.y * d_ggx * g2 / refl_denom,
             fc.z * d_ggx * g2 / refl_denom);
         f = f + contrib * lm.metal_wt;
         pdf += lm.metal_pr * refl_pdf;
     }
-    if (lm.glass_pr > 0.0f) {
+    if (kGlass && lm.glass_pr > 0.0f) {
         float const fr = dielectric_fresnel(abs_v_h, si.eta);
         if (reflect) {
             if (l.z > 0.0f) {
@@ -435,7 +467,7 @@ RT_DEV f4 eval_disney(hit_state const& st, surface const& si, lobe_mix const& lm
         }
     }
     // clearcoat, :152-168
-    if (lm.clearcoat_pr > 0.0f && reflect && l.z > 0.0f) {
+    if (kClearcoat && lm.clearcoat_pr > 0.0f && reflect && l.z > 0.0f) {
         float const v_h = dot3(v, h);
         float const fc = mix1(0.04f, 1.0f, schlick_weight(v_h));
         float const d = gtr1(h.z, si.clearcoat_gloss);
@@ -459,8 +491,13 @@ RT_DEV f3 refract3(f3 i, f3 n, float eta) {
 }
 
 // sample_disney, :250-315.  Returns the sampled world-space direction.
+template <uint32_t F = kShadeAll>
 RT_DEV f3 sample_disney(uint32_t& seed, hit_state const& st, surface const& si,
     lobe_mix const& lm) {
+    // Without a glass material glass_pr is zero, cdf3 == cdf2 and the Fresnel draw never
+    // happens.  The clearcoat branch stays whatever the scene holds: the four probabilities
+    // can add up to a float just below one, and a draw of pr at or above it lands there.
+    constexpr bool kGlass = feat<F>(kFeatGlass);
     f3 const v = lm.v;
     float const cdf0 = lm.diffuse_pr;
     float const cdf1 = cdf0 + lm.dielectric_pr;
@@ -483,7 +520,7 @@ RT_DEV f3 sample_disney(uint32_t& seed, hit_state const& st, surface const& si,
             h = -h;
         }
         bool do_reflect = true;
-        if (!(pr < cdf2)) {
+        if (kGlass && !(pr < cdf2)) {
             float const fr = dielectric_fresnel(fabsf(dot3(v, h)), si.eta);
             float const pr_f = rand_01(seed);
             do_reflect = pr_f < fr;
@@ -501,13 +538,14 @@ RT_DEV f3 sample_disney(uint32_t& seed, hit_state const& st, surface const& si,
 
 // ---------------------------------------------------------------------------
 // eval_sky_light, megakernel_raytracer.comp:413-438.  Returns (radiance, pdf).
+template <uint32_t F = kShadeAll>
 RT_DEV f4 eval_sky_light(scene_dev const& sc, f3 direction) {
-    if (sc.sky_light < 0) {
+    if (!feat<F>(kFeatSky) || sc.sky_light < 0) {
         return f4{0.0f, 0.0f, 0.0f, 0.0f};
     }
     rt_light const& sky = sc.lights[sc.sky_light];
     f3 const intensity = mk3(sky.intensity[0], sky.intensity[1], sky.intensity[2]);
-    if (sky.emission_tex < 0) {
+    if (!feat<F>(kFeatTextures) || sky.emission_tex < 0) {
         return f4{intensity.x, intensity.y, intensity.z, kOneOverFourPi};
     }
     float const theta = acosf(clamp1(direction.y, -1.0f, 1.0f));

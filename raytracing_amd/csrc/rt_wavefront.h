@@ -43,7 +43,9 @@ enum : uint32_t {
     kCtlClosest = 1,  // entries in this trip's closest-hit ray queue
     kCtlShadow = 2,   // entries in this trip's occlusion ray queue
     kCtlFinish = 3,   // entries of the live list handed to the finishing kernel instead
-    kCtlWords = 4,
+    kCtlRegionCursor = 4,  // next batch of regions of the `going` list to be shaded (wf_shade_kernel)
+    kCtlGoing = 5,         // paths on the `going` list
+    kCtlWords = 8,
 };
 
 // Per-wave work counters (wave_stats[slot][k]); slot = wave index in its launch.
@@ -92,6 +94,9 @@ struct wavefront_params {
     uint32_t* q_closest;     // compacted pids with a closest-hit ray
     uint32_t* q_shadow;      // compacted pids with an occlusion ray
     uint32_t* raw;           // per input slot: pid | flags of the surviving path, or 0
+    uint2* going;            // per region of kRegionSlots list slots: (slot, entry) of the paths
+                             // the shading kernel has to shade, packed at the region's start
+    uint32_t* going_count;   // per region: how many
     uint32_t* chunk_counts;  // per 64 raw slots: live | closest << 8 | shadow << 16
     uint32_t* tile_sums;     // per 1024 chunks: 3 words, sums and then offsets of the tile
     uint32_t* control;       // [trip][kCtlWords]
@@ -117,6 +122,8 @@ struct wavefront_params {
     uint32_t frame_width;
     uint32_t x0, y0, x1, y1;
     uint32_t blocks_x, block_count;  // 8x8 blocks covering the rectangle
+    uint32_t padded;                 // the rectangle's sides are not multiples of 8: some lanes
+                                     // of its 8x8 blocks have no pixel
     uint32_t tile_width, tile_height, tiles_x, tile_count;
     uint32_t pass_count;             // passes in this batch
     uint32_t max_depth;
@@ -140,6 +147,14 @@ RT_DEV float2 stream_load(const float2* p) {
     return make_float2(v.x, v.y);
 }
 RT_DEV uint32_t stream_load(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+// The first three floats of a float4 (a ray's origin or direction: the fourth is unused).  A
+// four-float load whose last register is dead lets the compiler reuse that register at once,
+// and the write then has to wait for the load: a prefetch would stall its issuer.
+typedef float native_f3 __attribute__((ext_vector_type(3)));
+RT_DEV f3 stream_load3(const float4* p) {
+    native_f3 const v = __builtin_nontemporal_load(reinterpret_cast<const native_f3*>(p));
+    return mk3(v.x, v.y, v.z);
+}
 RT_DEV void stream_store(float4* p, float4 v) {
     native_f4 n;
     n.x = v.x, n.y = v.y, n.z = v.z, n.w = v.w;
@@ -155,22 +170,6 @@ RT_DEV void stream_store(uint32_t* p, uint32_t v) { __builtin_nontemporal_store(
 // Index of this wave in its launch and the number of waves launched.
 RT_DEV uint32_t wave_index() { return (blockIdx.x * blockDim.x + threadIdx.x) >> 6; }
 RT_DEV uint32_t wave_total() { return (gridDim.x * blockDim.x) >> 6; }
-
-// Publishes one raw slot per lane and the chunk's packed counts.
-RT_DEV void publish_raw(wavefront_params const& p, uint32_t chunk, uint32_t slot, bool in_range,
-    uint32_t entry) {
-    unsigned long long const live = __ballot(entry != 0u);
-    unsigned long long const closest = __ballot((entry & kLiveHasClosest) != 0u);
-    unsigned long long const shadow = __ballot((entry & kLiveHasShadow) != 0u);
-    if (in_range) {
-        p.raw[slot] = entry;
-    }
-    if (wave_lane() == 0) {
-        p.chunk_counts[chunk] = (uint32_t) __builtin_popcountll(live) |
-                                ((uint32_t) __builtin_popcountll(closest) << 8) |
-                                ((uint32_t) __builtin_popcountll(shadow) << 16);
-    }
-}
 
 RT_DEV void add_wave_stat(wavefront_params const& p, uint32_t k, unsigned long long v) {
     // one lane per wave, no other wave touches this slot
@@ -265,19 +264,37 @@ RT_DEV triple block_inclusive_scan(triple v, uint32_t (*scratch)[THREADS]) {
     return triple{scratch[0][t], scratch[1][t], scratch[2][t]};
 }
 
+// (1) also counts the raw slots, 64 at a time, and leaves the packed counts in chunk_counts:
+// the producers write raw words only, in any order and from several launches.
 __global__ void __launch_bounds__(kTileThreads) wf_tile_sums_kernel(wavefront_params const p,
     const uint32_t* in_count_ptr, uint32_t in_count) {
     __shared__ uint32_t scratch[3][kTileThreads];
+    __shared__ uint32_t packed[kTileChunks];
     uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
     uint32_t const chunks = (n + 63u) / 64u;
     uint32_t const first = blockIdx.x * kTileChunks;
     if (first >= chunks) {
         return;
     }
+    uint32_t const tile_chunks = min(kTileChunks, chunks - first);
+    for (uint32_t c = threadIdx.x >> 6; c < tile_chunks; c += kTileThreads / 64u) {
+        uint32_t const slot = (first + c) * 64u + wave_lane();
+        uint32_t const entry = slot < n ? stream_load(&p.raw[slot]) : 0u;
+        unsigned long long const live = __ballot(entry != 0u);
+        unsigned long long const closest = __ballot((entry & kLiveHasClosest) != 0u);
+        unsigned long long const shadow = __ballot((entry & kLiveHasShadow) != 0u);
+        if (wave_lane() == 0) {
+            uint32_t const counts = (uint32_t) __builtin_popcountll(live) |
+                                    ((uint32_t) __builtin_popcountll(closest) << 8) |
+                                    ((uint32_t) __builtin_popcountll(shadow) << 16);
+            packed[c] = counts;
+            p.chunk_counts[first + c] = counts;
+        }
+    }
+    __syncthreads();
     triple sum{0u, 0u, 0u};
-    for (uint32_t c = first + threadIdx.x; c < min(first + kTileChunks, chunks);
-         c += kTileThreads) {
-        triple const v = unpack_counts(p.chunk_counts[c]);
+    for (uint32_t c = threadIdx.x; c < tile_chunks; c += kTileThreads) {
+        triple const v = unpack_counts(packed[c]);
         sum.live += v.live;
         sum.closest += v.closest;
         sum.shadow += v.shadow;
@@ -789,15 +806,38 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
     }
 }
 
-// Shades every live path of trip `trip`; survivors are published as raw slots for the
-// compaction that builds trip + 1's lists.
+// Shading of trip `trip`, in two launches over its live list (trip 0: over all pids).
 //
-// Workgroups of kShadeThreads threads; each first copies the scene's small tables into LDS
-// (plan_shade_tables) and points its copy of the scene description at them, so the shading
-// code reads them through the same pointers either way.
+// What a path costs here differs by two orders of magnitude.  A path whose ray hit a surface
+// below max_depth goes on: light proposal, BSDF sampling, two BSDF evaluations - a few thousand
+// instructions in some 200 registers (two waves per SIMD).  Every other path ENDS here - it had
+// no closest-hit ray, missed, hit a light or is at max_depth - after a few dozen instructions
+// that mostly wait for memory; after the first bounce of an open scene that is nine paths in
+// ten.  Shading both kinds in one kernel made the many cheap paths run at the occupancy of
+// the few dear ones (measured inside that kernel: 50-64 % of a later bounce's time went into
+// fetching list entries and path state, i.e. into memory latency at two waves per SIMD).
+//
+//   wf_settle_kernel  sorts the list: it settles the paths that end (their radiance becomes
+//                     final, their raw slot 0) and writes the others, region by region of
+//                     kRegionSlots list slots, to the `going` list.  Small, up to eight waves
+//                     per SIMD: it runs at the speed of the memory system.
+//   wf_shade_kernel   shades the going paths, 64 per wave whatever their slots were, and
+//                     writes their raw slots.  Waves take regions from a counter in the
+//                     control block (one atomic per region, not per chunk).
+//
+// Which lane shades which path has no influence on any result; both kernels call shade_trip,
+// each with the half of it that its paths can reach.  The compaction that follows counts the
+// raw slots itself (wf_tile_sums_kernel).
+//
+// Both stage the scene's small tables in LDS first (plan_shade_tables) and point their copy of
+// the scene description at them.
 constexpr uint32_t kShadeThreads = 256;
+constexpr uint32_t kSettleThreads = 1024;
+constexpr uint32_t kRegionSlots = 1024;
+#ifdef RT_SHADE_REGION_TIMING
+__device__ unsigned long long g_region_cycles[2][12];
+#endif
 
-// FIRST: trip 0 - the live paths are pids 0 .. paths-1 with their initial state.
 #ifndef RT_SHADE_WAVES_PER_SIMD
 #define RT_SHADE_WAVES_PER_SIMD 2
 #endif
@@ -806,231 +846,379 @@ constexpr uint32_t kShadeThreads = 256;
 #define RT_SHADE_GROUPS_PER_CU RT_SHADE_WAVES_PER_SIMD
 #endif
 constexpr uint32_t kShadeGroupsPerCu = RT_SHADE_GROUPS_PER_CU;
-// 0: experiments - leave the scene's small tables in memory (1.5-3 % slower on the test scenes)
-#ifndef RT_SHADE_STAGE
-#define RT_SHADE_STAGE 1
+// settle: 1024-thread workgroups; two per CU = eight waves per SIMD when the registers allow
+#ifndef RT_SETTLE_GROUPS_PER_CU
+#define RT_SETTLE_GROUPS_PER_CU 2
 #endif
-// A wave regroups the paths of this many chunks at a time by what shading them costs (see the
-// kernel); its two lists and the results take 8 bytes of LDS per slot.
-#ifndef RT_SHADE_SPAN_CHUNKS
-#define RT_SHADE_SPAN_CHUNKS 8
-#endif
-constexpr uint32_t kSpanChunks = RT_SHADE_SPAN_CHUNKS;
-constexpr uint32_t kSpanSlots = kSpanChunks * 64u;
-constexpr uint32_t kShadeRegroupLds = (kShadeThreads / 64u) * kSpanSlots * 8u;
-constexpr uint32_t kShadeLdsBudget =
-    (kShadeGroupsPerCu <= 2u ? 80u : 53u) * 1024u - kShadeRegroupLds;
-template <bool FIRST>
+constexpr uint32_t kSettleGroupsPerCu = RT_SETTLE_GROUPS_PER_CU;
+constexpr uint32_t kShadeLdsBudget = (kShadeGroupsPerCu <= 2u ? 64u : 48u) * 1024u;
+
+// Copies the tables the plan stages into `lds` and returns the scene description that points
+// at the copies.  Called by every thread of the workgroup; ends with a barrier.
+RT_DEV scene_dev stage_scene_tables(scene_dev const& global, float4* lds, uint32_t threads) {
+    scene_dev sc = global;
+    shade_plan const plan = plan_shade_tables(global, kShadeLdsBudget);
+    const void* const source[kTableCount] = {global.lights, global.materials, global.meshes,
+        global.textures, global.instances, global.transforms, global.normal_matrices};
+    uint32_t* const words = reinterpret_cast<uint32_t*>(lds);
+    for (uint32_t t = 0; t < kTableCount; ++t) {
+        if (plan.offset[t] == kNotStaged) {
+            continue;
+        }
+        const uint32_t* const src = static_cast<const uint32_t*>(source[t]);
+        for (uint32_t i = threadIdx.x; i < plan.bytes[t] / 4u; i += threads) {
+            words[plan.offset[t] / 4u + i] = src[i];
+        }
+    }
+    __syncthreads();
+    auto staged = [&](uint32_t t, const void* fallback) -> const void* {
+        return plan.offset[t] == kNotStaged
+                   ? fallback
+                   : static_cast<const void*>(reinterpret_cast<const char*>(lds) + plan.offset[t]);
+    };
+    sc.lights = static_cast<const rt_light*>(staged(kTableLights, global.lights));
+    sc.materials = static_cast<const rt_material*>(staged(kTableMaterials, global.materials));
+    sc.meshes = static_cast<const rt_mesh*>(staged(kTableMeshes, global.meshes));
+    sc.textures = static_cast<const texture_dev*>(staged(kTableTextures, global.textures));
+    sc.instances = static_cast<const rt_instance*>(staged(kTableInstances, global.instances));
+    sc.transforms = static_cast<const rt_mat4*>(staged(kTableTransforms, global.transforms));
+    sc.normal_matrices =
+        static_cast<const normal_matrix*>(staged(kTableNormalMatrices, global.normal_matrices));
+    return sc;
+}
+
+// FIRST: trip 0 - the list is pids 0 .. paths-1, every path has a closest-hit ray and its
+// initial state (nothing has been stored yet).
+template <bool FIRST, uint32_t F>
+__global__ void __launch_bounds__(kSettleThreads, RT_SETTLE_GROUPS_PER_CU * 4)
+    wf_settle_kernel(wavefront_params const p, uint32_t trip) {
+    extern __shared__ float4 shade_lds[];
+    uint32_t const n_live =
+        FIRST ? p.pass_count * p.block_count * 64u : p.control[trip * kCtlWords + kCtlLive];
+    uint32_t const total_regions = (n_live + kRegionSlots - 1u) / kRegionSlots;
+    if (blockIdx.x * (kSettleThreads / 64u) >= total_regions) {
+        return;  // none of this workgroup's waves has a region
+    }
+    scene_dev const sc = stage_scene_tables(p.sc, shade_lds, kSettleThreads);
+    // a traced path's depth is the trip's number: every trip it went through added one
+    bool const last_trip = trip == p.max_depth;
+    unsigned long long const below = (1ull << wave_lane()) - 1ull;
+    uint32_t total_hits = 0, samples = 0, total_going = 0;
+    for (uint32_t region = wave_index(); region < total_regions; region += wave_total()) {
+        uint32_t const first_slot = region * kRegionSlots;
+        uint32_t const region_chunks = (min(n_live - first_slot, kRegionSlots) + 63u) / 64u;
+        uint32_t going = 0;
+        for (uint32_t k = 0; k < region_chunks; ++k) {
+            uint32_t const i = first_slot + k * 64u + wave_lane();
+            bool const in_range = i < n_live;
+            uint32_t const entry =
+                FIRST ? (i | kLiveHasClosest) : (in_range ? stream_load(&p.live[i]) : 0u);
+            uint32_t const pid = entry & kLivePidMask;
+            bool traced = in_range && (entry & kLiveHasClosest) != 0u;
+            bool real = in_range;
+            if (FIRST && p.padded != 0u && in_range) {
+                // the padding lanes of partial 8x8 blocks have no path and no hit record
+                uint32_t x, y, pass;
+                real = traced = pid_pixel(p, pid, x, y, pass);
+            }
+            float4 h0 = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            bool hit = false, goes_on = false;
+            if (traced) {
+                h0 = stream_load(&p.hit0[pid]);
+                uint32_t const instance = __float_as_uint(h0.x);
+                hit = instance != RT_HIP_MISS;
+                goes_on = hit && !last_trip && sc.instances[instance].light < 0;
+            }
+            unsigned long long const going_mask = __ballot(goes_on);
+            if (goes_on) {
+                p.going[first_slot + going + (uint32_t) __builtin_popcountll(going_mask & below)] =
+                    make_uint2(i, entry);
+            }
+            going += (uint32_t) __builtin_popcountll(going_mask);
+            if (in_range && !goes_on) {
+                stream_store(&p.raw[i], 0u);  // the path ends here (or never was)
+            }
+            if (FIRST && real) {
+                samples += 1u;
+            }
+            if (!real || goes_on) {
+                continue;
+            }
+            // The path ends at this trip; its radiance becomes final.  Only what the case at
+            // hand reads is fetched: the waves here are many and wait for memory, not for the
+            // VALU, so a dependent load costs less than the bytes of an unconditional one.
+            bool const has_shadow = !FIRST && (entry & kLiveHasShadow) != 0u;
+            bool const lit = has_shadow && stream_load(&p.occluded[pid]) == 0u;
+            bool const sky = traced && !hit && feat<F>(kFeatSky) && sc.sky_light >= 0;
+            if (!FIRST && !lit && !sky && !hit) {
+                continue;  // nothing is added: rad[pid] is final as it stands
+            }
+            ray_pair rp;
+            rp.has_shadow = has_shadow;
+            rp.has_closest = traced;
+            rp.origin = rp.direction = splat3(0.0f);
+            path_state ps;
+            ps.radiance = splat3(0.0f);
+            ps.throughput = splat3(1.0f);
+            ps.nee = splat3(0.0f);
+            ps.last_bsdf_pdf = 0.0f;
+            ps.depth = trip;
+            ps.seed = 0u;
+            pair_result pr;
+            pr.occluded = !lit;
+            pr.hit = hit;
+            if (FIRST) {
+                if (sky || hit) {
+                    primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
+                }
+            } else {
+                float4 const rad = stream_load(&p.rad[pid]);
+                ps.radiance = mk3(rad.x, rad.y, rad.z);
+                if (lit || sky) {
+                    float4 const nee = stream_load(&p.nee[pid]);
+                    ps.nee = mk3(nee.x, nee.y, nee.z);
+                    ps.last_bsdf_pdf = nee.w;
+                }
+                if (sky || hit) {
+                    float4 const thr = stream_load(&p.thr[pid]);
+                    float4 const d = stream_load(&p.ray_d[pid]);
+                    ps.throughput = mk3(thr.x, thr.y, thr.z);
+                    rp.direction = mk3(d.x, d.y, d.z);
+                }
+                if (hit) {
+                    float4 const o = stream_load(&p.ray_o[pid]);
+                    rp.origin = mk3(o.x, o.y, o.z);
+                }
+            }
+            if (hit) {
+                float2 const h1 = stream_load(&p.hit1[pid]);
+                pr.best.instance = __float_as_uint(h0.x);
+                pr.best.triangle = __float_as_uint(h0.y);
+                pr.best.b0 = h0.z;
+                pr.best.b1 = h0.w;
+                pr.best.b2 = h1.x;
+                pr.best.t = h1.y;
+            }
+            uint32_t closest_hits = 0, shadow_skipped = 0;
+            shade_trip<F, kTripEnds>(sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
+            total_hits += closest_hits;
+            stream_store(&p.rad[pid], make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
+                                          __uint_as_float(ps.depth)));
+        }
+        if (wave_lane() == 0) {
+            p.going_count[region] = going;
+        }
+        total_going += going;
+    }
+    if (wave_lane() == 0 && total_going != 0u) {
+        atomicAdd(p.control + trip * kCtlWords + kCtlGoing, total_going);
+    }
+    unsigned long long const hits = wave_sum(total_hits);
+    unsigned long long const started = FIRST ? wave_sum(samples) : 0ull;
+    if (wave_lane() == 0) {
+        add_wave_stat(p, kStatClosestHits, hits);
+        if (FIRST) {
+            add_wave_stat(p, kStatSamples, started);  // = trip 0's closest-hit rays, too
+        }
+    }
+}
+
+// What wf_shade_kernel holds of a going path before it shades it.
+struct going_state {
+    float4 rad, thr, nee, h0;
+    f3 o, d;
+    float2 h1;
+    uint32_t occluded;
+};
+
+template <bool FIRST, uint32_t F>
 __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
     wf_shade_kernel(wavefront_params const p, uint32_t trip) {
     extern __shared__ float4 shade_lds[];
     uint32_t const n_live =
         FIRST ? p.pass_count * p.block_count * 64u : p.control[trip * kCtlWords + kCtlLive];
-    uint32_t const total_chunks = (n_live + 63u) / 64u;
-    if (blockIdx.x * (kShadeThreads / 64u) >= total_chunks) {
-        return;  // none of this workgroup's waves has a chunk
+    uint32_t const going_total = p.control[trip * kCtlWords + kCtlGoing];
+    if (going_total == 0u) {
+        return;
     }
-    scene_dev sc = p.sc;
-    if (RT_SHADE_STAGE) {
-        shade_plan const plan = plan_shade_tables(p.sc, kShadeLdsBudget);
-        const void* const source[kTableCount] = {p.sc.lights, p.sc.materials, p.sc.meshes,
-            p.sc.textures, p.sc.instances, p.sc.transforms, p.sc.normal_matrices};
-        uint32_t* const words = reinterpret_cast<uint32_t*>(shade_lds);
-        for (uint32_t t = 0; t < kTableCount; ++t) {
-            if (plan.offset[t] == kNotStaged) {
-                continue;
-            }
-            const uint32_t* const src = static_cast<const uint32_t*>(source[t]);
-            for (uint32_t i = threadIdx.x; i < plan.bytes[t] / 4u; i += kShadeThreads) {
-                words[plan.offset[t] / 4u + i] = src[i];
+    // A wave takes a BATCH of `span` consecutive regions at a time and shades their going paths
+    // as one dense sequence, 64 per step, whatever region each came from: where one path in
+    // fifteen goes on, a region alone would fill a wave once, partly.  `span` is chosen so that
+    // a batch holds about kBatchPaths going paths on average - few enough that the batches
+    // outnumber the waves many times over (waves take them from a counter, so the load
+    // balances), enough that what a wave pays per batch (the counter, the counts, an empty
+    // pipeline) stays small.
+    constexpr uint32_t kBatchPaths = 1024;
+    uint32_t const total_regions = (n_live + kRegionSlots - 1u) / kRegionSlots;
+    uint32_t const span = (uint32_t) min(
+        64ull, max(1ull, ((unsigned long long) kBatchPaths * total_regions + going_total - 1u) /
+                             going_total));
+    uint32_t const total_batches = (total_regions + span - 1u) / span;
+    if (blockIdx.x * (kShadeThreads / 64u) >= total_batches) {
+        return;  // the waves before this workgroup's can take every batch there is
+    }
+    scene_dev const sc = stage_scene_tables(p.sc, shade_lds, kShadeThreads);
+    uint32_t* const cursor = p.control + trip * kCtlWords + kCtlRegionCursor;
+    uint32_t total_hits = 0, total_skipped = 0;
+    region_clock rc;
+    rc.start();
+    for (;;) {
+        uint32_t batch = 0;
+        if (wave_lane() == 0) {
+            batch = atomicAdd(cursor, 1u);
+        }
+        batch = (uint32_t) __builtin_amdgcn_readfirstlane((int) batch);
+        if (batch >= total_batches) {
+            break;
+        }
+        // lane j: going paths of the batch's regions before its j-th (exclusive prefix sum)
+        uint32_t const first_region = batch * span;
+        uint32_t const my_region = first_region + wave_lane();
+        uint32_t const mine =
+            wave_lane() < span && my_region < total_regions ? p.going_count[my_region] : 0u;
+        uint32_t before = mine;
+        for (uint32_t step = 1; step < 64u; step <<= 1) {
+            uint32_t const other = (uint32_t) __shfl_up((int) before, step, 64);
+            if (wave_lane() >= step) {
+                before += other;
             }
         }
-        __syncthreads();
-        auto staged = [&](uint32_t t, const void* fallback) -> const void* {
-            return plan.offset[t] == kNotStaged
-                       ? fallback
-                       : static_cast<const void*>(reinterpret_cast<const char*>(shade_lds) +
-                                                  plan.offset[t]);
+        uint32_t const count = (uint32_t) __builtin_amdgcn_readlane((int) before, 63);
+        before -= mine;
+        // the (slot, entry) pair at position `at` of the batch's dense sequence
+        auto item_at = [&](uint32_t at) {
+            uint32_t j = 0;  // the last region whose prefix is <= at
+            for (uint32_t step = 32u; step > 0u; step >>= 1) {
+                uint32_t const probe = j + step;
+                uint32_t const prefix = (uint32_t) __shfl((int) before, (int) (probe & 63u), 64);
+                if (probe < span && prefix <= at) {
+                    j = probe;
+                }
+            }
+            uint32_t const prefix = (uint32_t) __shfl((int) before, (int) j, 64);
+            if (at >= count) {
+                return make_uint2(0u, 0u);
+            }
+            return p.going[(size_t) (first_region + j) * kRegionSlots + (at - prefix)];
         };
-        sc.lights = static_cast<const rt_light*>(staged(kTableLights, p.sc.lights));
-        sc.materials = static_cast<const rt_material*>(staged(kTableMaterials, p.sc.materials));
-        sc.meshes = static_cast<const rt_mesh*>(staged(kTableMeshes, p.sc.meshes));
-        sc.textures = static_cast<const texture_dev*>(staged(kTableTextures, p.sc.textures));
-        sc.instances = static_cast<const rt_instance*>(staged(kTableInstances, p.sc.instances));
-        sc.transforms = static_cast<const rt_mat4*>(staged(kTableTransforms, p.sc.transforms));
-        sc.normal_matrices = static_cast<const normal_matrix*>(
-            staged(kTableNormalMatrices, p.sc.normal_matrices));
-    }
-    const uint32_t* const live = p.live;
-    uint32_t total_hits = 0, total_skipped = 0, samples = 0;
-    // Regrouping inside the wave.  Shading a path that hit a surface and goes on (light
-    // proposal, BSDF sampling, two BSDF evaluations) costs a few thousand instructions; a path
-    // that missed, hit a light or reached max_depth costs a few dozen.  A wave pays for the
-    // dearest of its 64 lanes, and after the first bounce of an open scene nine paths in ten
-    // are of the cheap kind while nearly every chunk of 64 holds one of the other.  So a wave
-    // takes kSpanChunks chunks at a time, sorts their entries into a cheap and a dear list
-    // (LDS, ballot ranks - no atomics), shades each list 64 entries at a time, and then
-    // publishes the results in the entries' original slots: which lane shades which path has
-    // no influence on any result, and the raw slots and chunk counts come out as before.
-    __shared__ uint16_t s_list[kShadeThreads / 64u][2][kSpanSlots];   // [wave][cheap, dear]
-    __shared__ uint32_t s_result[kShadeThreads / 64u][kSpanSlots];    // [wave][slot of the span]
-    uint16_t(*const list)[kSpanSlots] = s_list[threadIdx.x >> 6];
-    uint32_t* const result = s_result[threadIdx.x >> 6];
-    unsigned long long const below = (1ull << wave_lane()) - 1ull;
-    uint32_t const total_spans = (total_chunks + kSpanChunks - 1u) / kSpanChunks;
-    for (uint32_t span = wave_index(); span < total_spans; span += wave_total()) {
-        uint32_t const first_slot = span * kSpanSlots;
-        // 1. classify
-        uint32_t count[2] = {0u, 0u};
-        for (uint32_t k = 0; k < kSpanChunks; ++k) {
-            uint32_t const local = k * 64u + wave_lane();
-            uint32_t const i = first_slot + local;
-            bool const in_range = i < n_live;
-            bool dear = false;
-            if (in_range) {
-                uint32_t const entry = FIRST ? (i | kLiveHasClosest) : live[i];
-                uint32_t const pid = entry & kLivePidMask;
-                bool traced = (entry & kLiveHasClosest) != 0u;
-                if (FIRST) {
-                    // the padding lanes of partial 8x8 blocks have no path and no hit record
-                    uint32_t x, y, pass;
-                    traced = pid_pixel(p, pid, x, y, pass);
+        auto fetch = [&](uint2 item, bool active, going_state& g) {
+            uint32_t const pid = item.y & kLivePidMask;
+            if (active) {
+                if (!FIRST) {
+                    g.rad = stream_load(&p.rad[pid]);
+                    g.thr = stream_load(&p.thr[pid]);
+                    g.nee = stream_load(&p.nee[pid]);
+                    g.o = stream_load3(&p.ray_o[pid]);
+                    g.d = stream_load3(&p.ray_d[pid]);
+                    g.occluded =
+                        (item.y & kLiveHasShadow) != 0u ? stream_load(&p.occluded[pid]) : 0u;
                 }
-                if (traced) {
-                    uint32_t const instance = __float_as_uint(p.hit0[pid].x);
-                    uint32_t const depth = FIRST ? 0u : __float_as_uint(p.rad[pid].w);
-                    dear = instance != RT_HIP_MISS && sc.instances[instance].light < 0 &&
-                           depth != p.max_depth;
-                }
+                g.h0 = stream_load(&p.hit0[pid]);
+                g.h1 = stream_load(&p.hit1[pid]);
             }
-            unsigned long long const dear_mask = __ballot(in_range && dear);
-            unsigned long long const cheap_mask = __ballot(in_range && !dear);
-            if (in_range) {
-                unsigned long long const mine = dear ? dear_mask : cheap_mask;
-                list[dear ? 1 : 0][count[dear ? 1 : 0] + (uint32_t) __builtin_popcountll(mine & below)] =
-                    (uint16_t) local;
-            }
-            count[0] += (uint32_t) __builtin_popcountll(cheap_mask);
-            count[1] += (uint32_t) __builtin_popcountll(dear_mask);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        // 2. shade: the cheap groups, then the dear groups
-        uint32_t const cheap_groups = (count[0] + 63u) / 64u;
-        uint32_t const groups = cheap_groups + (count[1] + 63u) / 64u;
-        for (uint32_t g = 0; g < groups; ++g) {
-            uint32_t const which = g < cheap_groups ? 0u : 1u;
-            uint32_t const at = (which ? g - cheap_groups : g) * 64u + wave_lane();
-            bool active = at < count[which];
-            uint32_t const local = active ? list[which][at] : 0u;
-            uint32_t const i = first_slot + local;
-            uint32_t const entry = FIRST ? (i | kLiveHasClosest) : (active ? live[i] : 0u);
+        };
+        rc.mark(8);
+        uint2 item = item_at(wave_lane());
+        going_state cur{};
+        fetch(item, wave_lane() < count, cur);
+        for (uint32_t at = wave_lane(); at - wave_lane() < count; at += 64u) {
+            bool const active = at < count;
+            // the next step's list entry is on its way while this step's path is set up; its
+            // state follows once this step has issued its last load (shade_trip's hook)
+            uint2 const next_item = item_at(at + 64u);
+            going_state next{};
+            struct prefetch {
+                decltype(fetch)& run;
+                uint2 item;
+                bool active;
+                going_state& into;
+                RT_DEV void after_loads() { run(item, active, into); }
+            } hook{fetch, next_item, at + 64u < count, next};
+            uint32_t const slot = item.x;
+            uint32_t const entry = item.y;
             uint32_t const pid = entry & kLivePidMask;
             ray_pair rp;
             rp.has_shadow = (entry & kLiveHasShadow) != 0u;
-            rp.has_closest = (entry & kLiveHasClosest) != 0u;
+            rp.has_closest = active;
             uint32_t closest_hits = 0, shadow_skipped = 0;
             path_state ps;
-            bool const listed = active;
-            if (FIRST && active) {
-                active = primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
-                ps.radiance = splat3(0.0f);
-                ps.throughput = splat3(1.0f);
-                ps.nee = splat3(0.0f);
-                ps.last_bsdf_pdf = 0.0f;
-                ps.depth = 0;
-                samples += active ? 1u : 0u;
-            }
             if (active) {
-                if (!FIRST) {
-                    float4 const rad = p.rad[pid];
-                    float4 const thr = p.thr[pid];
-                    float4 const nee = p.nee[pid];
-                    ps.radiance = mk3(rad.x, rad.y, rad.z);
-                    ps.depth = __float_as_uint(rad.w);
-                    ps.throughput = mk3(thr.x, thr.y, thr.z);
-                    ps.seed = __float_as_uint(thr.w);
-                    ps.nee = mk3(nee.x, nee.y, nee.z);
-                    ps.last_bsdf_pdf = nee.w;
-                }
                 pair_result pr;
-                pr.occluded = rp.has_shadow && p.occluded[pid] != 0u;
-                pr.hit = false;
-                if (rp.has_closest) {
-                    if (!FIRST) {
-                        float4 const o = p.ray_o[pid];
-                        float4 const d = p.ray_d[pid];
-                        rp.origin = mk3(o.x, o.y, o.z);
-                        rp.direction = mk3(d.x, d.y, d.z);
-                    }
-                    float4 const h0 = p.hit0[pid];
-                    pr.best.instance = __float_as_uint(h0.x);
-                    pr.hit = pr.best.instance != RT_HIP_MISS;
-                    if (pr.hit) {
-                        float2 const h1 = p.hit1[pid];
-                        pr.best.triangle = __float_as_uint(h0.y);
-                        pr.best.b0 = h0.z;
-                        pr.best.b1 = h0.w;
-                        pr.best.b2 = h1.x;
-                        pr.best.t = h1.y;
-                    }
+                pr.hit = true;
+                if (FIRST) {
+                    primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
+                    ps.radiance = splat3(0.0f);
+                    ps.throughput = splat3(1.0f);
+                    ps.nee = splat3(0.0f);
+                    ps.last_bsdf_pdf = 0.0f;
+                    ps.depth = 0;
+                    pr.occluded = false;
+                } else {
+                    pr.occluded = rp.has_shadow && cur.occluded != 0u;
+                    ps.radiance = mk3(cur.rad.x, cur.rad.y, cur.rad.z);
+                    ps.depth = __float_as_uint(cur.rad.w);
+                    ps.throughput = mk3(cur.thr.x, cur.thr.y, cur.thr.z);
+                    ps.seed = __float_as_uint(cur.thr.w);
+                    ps.nee = mk3(cur.nee.x, cur.nee.y, cur.nee.z);
+                    ps.last_bsdf_pdf = cur.nee.w;
+                    rp.origin = cur.o;
+                    rp.direction = cur.d;
                 }
-                shade_trip(sc, p.max_depth, rp, pr, ps, closest_hits, shadow_skipped);
-                p.rad[pid] = make_float4(ps.radiance.x, ps.radiance.y, ps.radiance.z,
-                    __uint_as_float(ps.depth));
+                pr.best.instance = __float_as_uint(cur.h0.x);
+                pr.best.triangle = __float_as_uint(cur.h0.y);
+                pr.best.b0 = cur.h0.z;
+                pr.best.b1 = cur.h0.w;
+                pr.best.b2 = cur.h1.x;
+                pr.best.t = cur.h1.y;
+                rc.mark(0);
+                shade_trip<F, kTripGoesOn>(sc, p.max_depth, rp, pr, ps, closest_hits,
+                    shadow_skipped, rc, hook);
+                rc.mark(11);
+                stream_store(&p.rad[pid], make_float4(ps.radiance.x, ps.radiance.y,
+                                              ps.radiance.z, __uint_as_float(ps.depth)));
                 if (rp.has_closest || rp.has_shadow) {
-                    p.thr[pid] = make_float4(ps.throughput.x, ps.throughput.y, ps.throughput.z,
-                        __uint_as_float(ps.seed));
-                    p.nee[pid] = make_float4(ps.nee.x, ps.nee.y, ps.nee.z, ps.last_bsdf_pdf);
+                    stream_store(&p.thr[pid], make_float4(ps.throughput.x, ps.throughput.y,
+                                                  ps.throughput.z, __uint_as_float(ps.seed)));
+                    stream_store(&p.nee[pid],
+                        make_float4(ps.nee.x, ps.nee.y, ps.nee.z, ps.last_bsdf_pdf));
                 }
                 if (rp.has_closest) {
-                    p.ray_o[pid] = make_float4(rp.origin.x, rp.origin.y, rp.origin.z, 0.0f);
-                    p.ray_d[pid] = make_float4(rp.direction.x, rp.direction.y, rp.direction.z, 0.0f);
+                    stream_store(&p.ray_o[pid],
+                        make_float4(rp.origin.x, rp.origin.y, rp.origin.z, 0.0f));
+                    stream_store(&p.ray_d[pid],
+                        make_float4(rp.direction.x, rp.direction.y, rp.direction.z, 0.0f));
                 }
                 if (rp.has_shadow) {
-                    p.sh_o[pid] = make_float4(rp.shadow_origin.x, rp.shadow_origin.y,
-                        rp.shadow_origin.z, rp.shadow_t_max);
-                    p.sh_d[pid] = make_float4(rp.shadow_direction.x, rp.shadow_direction.y,
-                        rp.shadow_direction.z, 0.0f);
+                    stream_store(&p.sh_o[pid], make_float4(rp.shadow_origin.x, rp.shadow_origin.y,
+                                                   rp.shadow_origin.z, rp.shadow_t_max));
+                    stream_store(&p.sh_d[pid], make_float4(rp.shadow_direction.x,
+                                                   rp.shadow_direction.y, rp.shadow_direction.z, 0.0f));
                 }
-            } else {
-                rp.has_shadow = false;
-                rp.has_closest = false;
-            }
-            if (listed) {
-                bool const goes_on = rp.has_closest || rp.has_shadow;
-                result[local] = goes_on ? (pid | (rp.has_closest ? kLiveHasClosest : 0u) |
-                                              (rp.has_shadow ? kLiveHasShadow : 0u))
-                                        : 0u;
+                bool const more = rp.has_closest || rp.has_shadow;
+                stream_store(&p.raw[slot],
+                    more ? (pid | (rp.has_closest ? kLiveHasClosest : 0u) |
+                               (rp.has_shadow ? kLiveHasShadow : 0u))
+                         : 0u);
             }
             total_hits += closest_hits;
             total_skipped += shadow_skipped;
+            item = next_item;
+            cur = next;
+            rc.mark(9);
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        // 3. publish, slot by slot as the compaction expects them
-        for (uint32_t k = 0; k < kSpanChunks; ++k) {
-            uint32_t const chunk = span * kSpanChunks + k;
-            if (chunk >= total_chunks) {
-                break;
-            }
-            uint32_t const local = k * 64u + wave_lane();
-            uint32_t const i = first_slot + local;
-            bool const in_range = i < n_live;
-            publish_raw(p, chunk, i, in_range, in_range ? result[local] : 0u);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        __builtin_amdgcn_wave_barrier();
     }
+#ifdef RT_SHADE_REGION_TIMING
+    if (wave_lane() == 0) {
+        for (int k = 0; k < 12; ++k) {
+            atomicAdd(&g_region_cycles[FIRST ? 0 : 1][k], rc.cycles[k]);
+        }
+    }
+#endif
     unsigned long long const hits = wave_sum(total_hits);
     unsigned long long const skipped = wave_sum(total_skipped);
-    unsigned long long const started = FIRST ? wave_sum(samples) : 0ull;
     if (wave_lane() == 0) {
         add_wave_stat(p, kStatClosestHits, hits);
         add_wave_stat(p, kStatShadowSkipped, skipped);
-        if (FIRST) {
-            add_wave_stat(p, kStatSamples, started);  // = trip 0's closest-hit rays, too
-        }
     }
 }
 
