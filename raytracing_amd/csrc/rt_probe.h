@@ -45,10 +45,15 @@ __global__ void __launch_bounds__(64) probe_kernel(scene_dev const sc, uint32_t 
         f3 const inv = splat3(1.0f) / d;
         r.u[0] = hit_aabb_ref(n, o, inv, d.x < 0.0f, d.y < 0.0f, d.z < 0.0f, q.f[12], q.f[13])
                      ? 1u : 0u;
-        // the rebuilt structure's slab test (one fma per plane, widened by 2 ulp), t_min = 0
+        // the rebuilt structure's slab test (one fma per plane, near / far planes picked by the
+        // sign of the direction as the walk does, widened on the exit side), t_min = 0
         float enter, exit;
-        slab_box(make_slab_ray(o, d), n.x_min, n.y_min, n.z_min, n.x_max, n.y_max, n.z_max,
-            q.f[13], enter, exit);
+        slab_ray const sr = make_slab_ray(o, d);
+        plane_offsets const po = make_plane_offsets(sr);
+        slab_box(sr, po.near_x == 0u ? n.x_min : n.x_max, po.near_y == 16u ? n.y_min : n.y_max,
+            po.near_z == 32u ? n.z_min : n.z_max, po.far_x == 0u ? n.x_min : n.x_max,
+            po.far_y == 16u ? n.y_min : n.y_max, po.far_z == 32u ? n.z_min : n.z_max, q.f[13],
+            enter, exit);
         r.u[1] = enter <= exit ? 1u : 0u;
         break;
     }
