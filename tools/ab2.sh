@@ -2,7 +2,7 @@
 # A/B of library builds on the bench with the per-kernel times: tools/ab2.sh "<bench args>" lib1.so lib2.so ...
 ARGS=$1; shift
 for l in "$@"; do
-  RT_HIP_LIB=$PWD/raytracing_amd/lib/$l timeout -k 10 200 python bench.py --no-cpu-baseline --steps 6 $ARGS 2>/dev/null | python -c "
+  RT_HIP_LIB=$PWD/raytracing_amd/lib/$l timeout -k 10 200 python bench.py --no-cpu-baseline --no-other-scenes --steps 6 $ARGS 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); r=d['roofline'] or {}
 print('$l', '$ARGS', round(d['value'],1), 'Msamples/s', round(d['ms_per_step'],2), 'ms; trace', round(r.get('extend_ms_per_call',0),2), 'shade', round(r.get('shade_ms_per_call',0),2))" || exit 1

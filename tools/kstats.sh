@@ -3,7 +3,7 @@
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${OUT}_stats -o s -- python3 $ROOT/bench.py --no-cpu-baseline --no-work-counters --steps 6 "$@" > $ROOT/gpurun_out/${OUT}.json 2> $ROOT/gpurun_out/${OUT}.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${OUT}_stats -o s -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-scenes --no-work-counters --steps 6 "$@" > $ROOT/gpurun_out/${OUT}.json 2> $ROOT/gpurun_out/${OUT}.err || exit 1
 python3 - <<PY
 import csv,glob
 for f in glob.glob("$ROOT/gpurun_out/${OUT}_stats/*kernel_stats.csv"):

@@ -15,7 +15,7 @@ for CTRS in \
   "FETCH_SIZE" \
   "WRITE_SIZE" ; do
   i=$((i+1))
-  timeout -s KILL 120 rocprofv3 --pmc $CTRS --output-format csv -d $ROOT/gpurun_out/${OUT}_p$i -o p -- python3 $ROOT/bench.py --no-cpu-baseline --no-work-counters --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${OUT}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $ROOT/gpurun_out/${OUT}_p$i.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $CTRS --output-format csv -d $ROOT/gpurun_out/${OUT}_p$i -o p -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-scenes --no-work-counters --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${OUT}_p$i.log 2>&1 || { echo "pass $i failed"; tail -5 $ROOT/gpurun_out/${OUT}_p$i.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, re

@@ -35,7 +35,7 @@ def main():
             write = c["WRITE_SIZE"] * 1024.0 / launches[k]["WRITE_SIZE"]
             bytes_per_launch[k] = fetch + write
         if "SQ_WAVE_CYCLES" in c and c["SQ_WAVE_CYCLES"] > 0 and k in (
-                "wf_extend_kernel", "wf_shade_kernel", "path_trace_kernel"):
+                "wf_extend_kernel", "wf_shade_kernel", "wf_settle_kernel", "path_trace_kernel"):
             # per-launch averages (some counters are collected in two passes)
             a = {name: value / launches[k][name] for name, value in c.items()}
             wc = a["SQ_WAVE_CYCLES"]

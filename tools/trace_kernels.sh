@@ -5,7 +5,7 @@ set -u
 OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/$OUT -o t -- python3 $ROOT/bench.py --no-cpu-baseline --steps 1 --warmup 1 "$@" > $ROOT/gpurun_out/$OUT.log 2>&1 || { tail -5 $ROOT/gpurun_out/$OUT.log; exit 1; }
+timeout -k 10 200 rocprofv3 --kernel-trace --output-format csv -d $ROOT/gpurun_out/$OUT -o t -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-scenes --steps 1 --warmup 1 "$@" > $ROOT/gpurun_out/$OUT.log 2>&1 || { tail -5 $ROOT/gpurun_out/$OUT.log; exit 1; }
 python3 - <<PY
 import csv, glob
 f = glob.glob("$ROOT/gpurun_out/$OUT/*kernel_trace.csv")[0]

@@ -4,7 +4,7 @@ OUT=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d $ROOT/gpurun_out/${OUT}_$C -o p -- python3 $ROOT/bench.py --no-cpu-baseline --no-work-counters --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${OUT}_$C.log 2>&1 || { echo "pass $C failed"; tail -5 $ROOT/gpurun_out/${OUT}_$C.log; exit 1; }
+  timeout -s KILL 120 rocprofv3 --pmc $C --output-format csv -d $ROOT/gpurun_out/${OUT}_$C -o p -- python3 $ROOT/bench.py --no-cpu-baseline --no-other-scenes --no-work-counters --steps 2 --warmup 1 "$@" > $ROOT/gpurun_out/${OUT}_$C.log 2>&1 || { echo "pass $C failed"; tail -5 $ROOT/gpurun_out/${OUT}_$C.log; exit 1; }
 done
 python3 - <<PY
 import csv, glob, collections, re
