@@ -152,6 +152,19 @@ int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pa
  * the reference, whose images and buffers are all created in prepare_data (:269-467). */
 int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t pass_count);
 
+/* Optional: settles, before the first render that counts, what rt_hip_render otherwise
+ * measures on its first two large calls (at least 2^22 paths each) after every scene upload:
+ * per bounce, whether the trace launch hands out rays in fixed chunks or refills finished
+ * lanes, and whether the ray queues are regrouped first.  Those two calls run 5-40 % below
+ * the speed of every later one (the first in fixed chunks throughout, the second refilling
+ * throughout); images never depend on the outcome.  This entry makes the same two calls -
+ * pass_count passes of the whole frame from `camera`, into a scratch image that is freed again,
+ * with a constant seed - and waits for each, so a render call that follows runs at the settled
+ * speed.  Accumulator and pass counter are untouched; the pipeline state is allocated as by
+ * rt_hip_reserve(width, height, pass_count).  pass_count x frame below 2^22 paths measures
+ * nothing (such calls always refill).  No counterpart in the reference. */
+int rt_hip_tune(rt_hip_renderer* r, const rt_camera* camera, uint32_t pass_count, void* stream);
+
 /* rt_hip_render for callers that cannot allocate device memory while they render: code under
  * HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  No counterpart in
  * the reference.  Same arguments, same result bit for bit, but the call allocates nothing,
@@ -209,6 +222,9 @@ int rt_hip_primary_ids(rt_hip_renderer* r, const rt_camera* camera, uint32_t pas
  *
  *   SKY_SAMPLE      u[0] = seed                      -> f[0..2] = direction drawn from the opt-in sky
  *                                                       distribution, f[3] = its pdf, u[0] = state after
+ *   TRIANGLE_DEGENERATE  f[0..8] = a b c             -> u[0] = hit_triangle's first test (ray.glsl:124-128:
+ *                                                       edge cross product shorter than 1e-8), the one
+ *                                                       rt_hip_triangle_never_hit evaluates on the host
  *
  * SAMPLE_TEXTURE, SKY and SKY_SAMPLE need an uploaded scene (SKY_SAMPLE one uploaded with
  * RT_HIP_FLAG_SKY_IMPORTANCE and an environment map); the others work on any renderer. */
@@ -222,7 +238,8 @@ enum {
     RT_HIP_PROBE_SAMPLE_DISNEY = 6,
     RT_HIP_PROBE_SAMPLE_TEXTURE = 7,
     RT_HIP_PROBE_SKY = 8,
-    RT_HIP_PROBE_SKY_SAMPLE = 9
+    RT_HIP_PROBE_SKY_SAMPLE = 9,
+    RT_HIP_PROBE_TRIANGLE_DEGENERATE = 10
 };
 typedef struct rt_hip_probe_in {
     uint32_t u[4];
@@ -235,6 +252,14 @@ typedef struct rt_hip_probe_out {
 } rt_hip_probe_out;
 int rt_hip_probe(rt_hip_renderer* r, uint32_t kind, uint32_t count, const rt_hip_probe_in* in,
     rt_hip_probe_out* out);
+
+/* Parity probe, host side (no counterpart in the reference): the test by which the rebuilt
+ * acceleration structure leaves triangles out of its leaves - hit_triangle's degenerate-triangle
+ * rejection (ray.glsl:124-128), evaluated once per triangle at upload with the device's float
+ * operations.  corners: 9 floats (a, b, c) per triangle; out[i] = 1 when triangle i can never be
+ * hit.  Must agree with RT_HIP_PROBE_TRIANGLE_DEGENERATE bit for bit: a disagreement would make
+ * the rebuilt mode hit a triangle the shader rejects, or lose one it hits. */
+int rt_hip_triangle_never_hit(const float* corners, uint32_t count, uint32_t* out);
 
 /* Synchronises `stream`, then copies the renderer's own accumulator (W*H*4 floats)
  * / preview image ((W/10)*(H/10)*4 floats) to the host.  *passes = number

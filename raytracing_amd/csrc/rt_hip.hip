@@ -462,6 +462,8 @@ struct rt_hip_renderer {
     uint32_t refill = RT_HIP_REFILL_UNDECIDED;
     double refill_ms[2] = {-1.0, -1.0};  // summed trace launches of the timed call: off, on
     std::vector<float> refill_trip_ms[2];  // the same per trip
+    std::vector<uint64_t> refill_trip_rays[2];  // rays those launches traced, per trip
+    size_t refill_base_paths = 0;          // paths per batch of the call that took the base line
     std::vector<uint8_t> refill_trip;      // the verdict per trip (trips beyond it: the last one's)
     uint32_t probe_kind = 0;           // what the probe in flight measures: 1 binning, 2 / 3 refill off / on
     bool bin_candidates = false;       // bin_trip holds the bounces whose rays are dear enough
@@ -811,6 +813,13 @@ void settle_binning(rt_hip_renderer& r) {
     r.binning = any ? RT_HIP_BINNING_ON : RT_HIP_BINNING_OFF;
 }
 
+// Rays the timed trace launch of bounce `trip` had in its two queues (from the copy of the
+// control block that the probe left in pinned memory).
+uint64_t probe_rays(rt_hip_renderer const& r, uint32_t trip) {
+    const uint32_t* const ctl = r.probe_counts + trip * kCtlWords;
+    return (uint64_t) ctl[kCtlClosest] + ctl[kCtlShadow];
+}
+
 // Settles an outstanding probe if its events have completed (never waits).
 void settle_probe(rt_hip_renderer& r) {
     if (!r.probe_pending || hipEventQuery(r.probe_done) != hipSuccess) {
@@ -821,20 +830,34 @@ void settle_probe(rt_hip_renderer& r) {
         int const mode = r.probe_kind == 3u ? 1 : 0;
         double total = 0.0;
         r.refill_trip_ms[mode].assign(r.probe_trips, 0.0f);
+        r.refill_trip_rays[mode].assign(r.probe_trips, 0);
         for (uint32_t trip = 0; trip < r.probe_trips; ++trip) {
             float ms = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, r.probe_events[2 * trip], r.probe_events[2 * trip + 1]));
             r.refill_trip_ms[mode][trip] = ms;
+            r.refill_trip_rays[mode][trip] = probe_rays(r, trip);
             total += (double) ms;
         }
         r.refill_ms[mode] = total;
         if (r.refill_ms[0] >= 0.0 && r.refill_ms[1] >= 0.0) {
-            // trip by trip: camera rays of one chunk walk alike, the rays of later bounces do not
+            // Trip by trip (camera rays of one chunk walk alike, the rays of later bounces do
+            // not), and per RAY: the two measurements come from two render calls, which may
+            // differ in passes, rectangle or camera, so the launch times as such do not compare.
             size_t const n = std::min(r.refill_trip_ms[0].size(), r.refill_trip_ms[1].size());
             r.refill_trip.assign(n, 0);
             bool any = false;
             for (size_t trip = 0; trip < n; ++trip) {
-                r.refill_trip[trip] = r.refill_trip_ms[1][trip] < r.refill_trip_ms[0][trip] ? 1 : 0;
+                uint64_t const rays_off = r.refill_trip_rays[0][trip];
+                uint64_t const rays_on = r.refill_trip_rays[1][trip];
+                if (rays_off == 0 || rays_on == 0) {
+                    // (a bounce that one of the calls handed to the finishing kernel: its launch
+                    // returned at once; follow the bounce before it)
+                    r.refill_trip[trip] = trip > 0 ? r.refill_trip[trip - 1] : 1;
+                } else {
+                    double const ns_off = (double) r.refill_trip_ms[0][trip] * 1e6 / (double) rays_off;
+                    double const ns_on = (double) r.refill_trip_ms[1][trip] * 1e6 / (double) rays_on;
+                    r.refill_trip[trip] = ns_on < ns_off ? 1 : 0;
+                }
                 any = any || r.refill_trip[trip] != 0;
             }
             r.refill = any ? RT_HIP_REFILL_ON : RT_HIP_REFILL_OFF;
@@ -850,6 +873,7 @@ void settle_probe(rt_hip_renderer& r) {
     r.bin_trip.assign(r.probe_trips, 0);
     if (refill_open) {
         r.refill_trip_ms[0].assign(r.probe_trips, 0.0f);
+        r.refill_trip_rays[0].assign(r.probe_trips, 0);
         r.refill_ms[0] = 0.0;
     }
     for (uint32_t trip = 0; trip < r.probe_trips; ++trip) {
@@ -857,6 +881,7 @@ void settle_probe(rt_hip_renderer& r) {
         HIP_CHECK(hipEventElapsedTime(&ms, r.probe_events[2 * trip], r.probe_events[2 * trip + 1]));
         if (refill_open) {
             r.refill_trip_ms[0][trip] = ms;
+            r.refill_trip_rays[0][trip] = probe_rays(r, trip);
             r.refill_ms[0] += (double) ms;
         }
         if (trip == 0u) {
@@ -1026,7 +1051,19 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         (r.binning != RT_HIP_BINNING_UNDECIDED || r.bin_candidates || trips <= 1u) &&
         r.refill == RT_HIP_REFILL_UNDECIDED && r.cfg.accel == RT_HIP_ACCEL_REBUILT) {
         probe = true;
-        probe_kind = r.refill_ms[0] < 0.0 ? 2u : 3u;
+        // the refilling call is compared with the base line per ray, but the two should still be
+        // of one order of size (launch tails, cache footprints): if this call's batch is not
+        // within a factor of two of the base line's, it becomes the base line instead
+        size_t const paths = per_pass * batch;
+        bool const comparable = r.refill_ms[0] >= 0.0 && 2u * paths >= r.refill_base_paths &&
+                                paths <= 2u * r.refill_base_paths;
+        probe_kind = comparable ? 3u : 2u;
+    }
+    if (probe && probe_kind != 3u) {
+        r.refill_base_paths = per_pass * batch;
+        if (probe_kind == 2u) {
+            r.refill_ms[0] = -1.0;
+        }
     }
     // undecided (small calls, the allocation-free entry point before any large call): refill
     bool const refill = probe_kind == 3u ||
@@ -1424,7 +1461,19 @@ void render_passes(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_p
     }
     p.pass_count = pass_count;
     p.seeds = r->seeds + (size_t) (first_pass - r->seeds_first_pass) * p.tile_count;
-    r->follow(stream);
+    // Under stream capture (the allocation-free entry point may be recorded into a HIP graph)
+    // the hand-over between streams is the capturing caller's business: an event recorded
+    // inside a capture must not be waited for by work outside it.
+    bool capturing = false;
+    if (allocation_free) {
+        hipStreamCaptureStatus status = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(stream, &status) == hipSuccess) {
+            capturing = status == hipStreamCaptureStatusActive;
+        }
+    }
+    if (!capturing) {
+        r->follow(stream);
+    }
     if (allocation_free) {
         if (p.max_depth > RT_HIP_NOALLOC_MAX_DEPTH) {
             throw std::runtime_error("render_noalloc: max_depth " + std::to_string(p.max_depth) +
@@ -1436,7 +1485,9 @@ void render_passes(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_p
     } else {
         launch_wavefront(*r, p, stream);
     }
-    r->mark(stream);
+    if (!capturing) {
+        r->mark(stream);
+    }
     if (!accum_dev && !rect) {
         r->passes_done += pass_count;
     }
@@ -1916,6 +1967,43 @@ int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t
     });
 }
 
+int rt_hip_tune(rt_hip_renderer* r, const rt_camera* camera, uint32_t pass_count, void* stream) {
+    return guarded([&] {
+        require_scene(r);
+        if (!camera || pass_count == 0) {
+            throw std::runtime_error("tune: null camera or no passes");
+        }
+        if (r->cfg.flags & RT_HIP_FLAG_FUSED) {
+            return;  // the fused kernel has no policies to settle
+        }
+        device_scope const on_device(r->device);
+        hipStream_t const s = (hipStream_t) stream;
+        float* scratch_accum = nullptr;
+        size_t const bytes = (size_t) r->cfg.width * r->cfg.height * 4u * sizeof(float);
+        HIP_CHECK(hipMalloc((void**) &scratch_accum, bytes));
+        try {
+            // the first large call is the fixed-chunk base line, the second refills its lanes;
+            // each is waited for, so that the verdict is in before the next one starts
+            for (uint32_t call = 0; call < 2u; ++call) {
+                render_params p = base_params(*r, *camera);
+                p.accum = scratch_accum;
+                p.pass_count = pass_count;
+                p.seeds = nullptr;
+                p.scalar_seed = 0x9E3779B9u + call;
+                r->follow(s);
+                launch_wavefront(*r, p, s);
+                r->mark(s);
+                HIP_CHECK(hipStreamSynchronize(s));
+                settle_probe(*r);
+            }
+        } catch (...) {
+            (void) hipFree(scratch_accum);
+            throw;
+        }
+        HIP_CHECK(hipFree(scratch_accum));
+    });
+}
+
 int rt_hip_render_noalloc(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
     uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream) {
     return guarded([&] {
@@ -2040,7 +2128,7 @@ int rt_hip_probe(rt_hip_renderer* r, uint32_t kind, uint32_t count, const rt_hip
         if (!r || !in || !out) {
             throw std::runtime_error("probe: null argument");
         }
-        if (kind > RT_HIP_PROBE_SKY_SAMPLE) {
+        if (kind > RT_HIP_PROBE_TRIANGLE_DEGENERATE) {
             throw std::runtime_error("probe: unknown kind");
         }
         if (count == 0) {
@@ -2092,6 +2180,23 @@ int rt_hip_probe(rt_hip_renderer* r, uint32_t kind, uint32_t count, const rt_hip
         }
         (void) hipFree(d_in);
         (void) hipFree(d_out);
+    });
+}
+
+int rt_hip_triangle_never_hit(const float* corners, uint32_t count, uint32_t* out) {
+    return guarded([&] {
+        if ((!corners || !out) && count > 0) {
+            throw std::runtime_error("triangle_never_hit: null argument");
+        }
+        for (uint32_t i = 0; i < count; ++i) {
+            rt_triangle tri{};
+            for (int k = 0; k < 3; ++k) {
+                tri.a.position_texu[k] = corners[9u * i + k];
+                tri.b.position_texu[k] = corners[9u * i + 3 + k];
+                tri.c.position_texu[k] = corners[9u * i + 6 + k];
+            }
+            out[i] = triangle_never_hit(tri) ? 1u : 0u;
+        }
     });
 }
 

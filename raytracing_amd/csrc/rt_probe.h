@@ -67,6 +67,10 @@ __global__ void __launch_bounds__(64) probe_kernel(scene_dev const sc, uint32_t 
         r.f[0] = b0, r.f[1] = b1, r.f[2] = b2, r.f[3] = t;
         break;
     }
+    case RT_HIP_PROBE_TRIANGLE_DEGENERATE:  // ray.glsl:124-128, the test the builder hoists
+        r.u[0] = degenerate_triangle(mk3(q.f[0], q.f[1], q.f[2]), mk3(q.f[3], q.f[4], q.f[5]),
+                     mk3(q.f[6], q.f[7], q.f[8])) ? 1u : 0u;
+        break;
     case RT_HIP_PROBE_EVAL_DISNEY:      // shaders/raytracer/disney.glsl:170-248
     case RT_HIP_PROBE_SAMPLE_DISNEY: {  // disney.glsl:250-315
         // the surface of megakernel_raytracer.comp:126-182 for a hit on this material alone

@@ -95,14 +95,20 @@ RT_DEV tri_ray make_tri_ray(f3 origin, f3 direction) {
 // check_degenerate = false: the caller knows the triangle passes the shader's first test
 // (|cross(edge1, edge2)| >= 1e-8, which does not depend on the ray): the rebuilt structure
 // leaves the triangles that fail it out of its leaves when it is built.
+// The first test of hit_triangle (ray.glsl:124-128): a triangle whose edge cross product is
+// shorter than 1e-8 is never hit, whatever the ray.  The rebuilt structure evaluates the same
+// test once per triangle on the host (accel_build.cpp: triangle_never_hit) and leaves such
+// triangles out of its leaves.
+RT_DEV bool degenerate_triangle(f3 a, f3 b, f3 c) {
+    f3 const edge1 = b - a;
+    f3 const edge2 = c - a;
+    return fabsf(length3(cross3(edge1, edge2))) < 1e-8f;
+}
+
 RT_DEV bool hit_triangle(f3 a, f3 b, f3 c, tri_ray const& ray, float t_max, float& b0,
     float& b1, float& b2, float& t, bool check_degenerate = true) {
-    if (check_degenerate) {
-        f3 const edge1 = b - a;
-        f3 const edge2 = c - a;
-        if (fabsf(length3(cross3(edge1, edge2))) < 1e-8f) {
-            return false;
-        }
+    if (check_degenerate && degenerate_triangle(a, b, c)) {
+        return false;
     }
     f3 const at0 = a - ray.origin;
     f3 const bt0 = b - ray.origin;

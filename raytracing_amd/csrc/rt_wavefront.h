@@ -572,12 +572,15 @@ __global__ void __launch_bounds__(kBinThreads) wf_bin_place_kernel(wavefront_par
     }
 }
 
-// Traces every ray of trip `trip`: chunks [0, closest_chunks) hold closest-hit rays, the
-// rest occlusion rays, so a wave never mixes the two kinds.  (A variant in which a lane that
-// finishes its ray takes the next one from the queue, instead of waiting for the slowest
-// ray of its chunk, measured no faster on incoherent rays and 1.8x slower on primary rays:
-// the refills expose the latency of the ray loads and repeat the per-ray set-up at partial
-// occupancy.)
+// Traces every ray of trip `trip`: first the closest-hit queue, then the occlusion queue, so
+// a wave never mixes the two kinds.  Two ways of handing the rays to the lanes, chosen per
+// launch by `refill` (the host measures both per uploaded scene and bounce, rt_hip.hip:
+// settle_probe): fixed chunks - a wave takes 64 rays and walks them to the end of the slowest -
+// or refilled lanes - every lane keeps a walk of its own, and once kRefillIdle lanes have
+// finished theirs they take the wave's next rays together (refilling lane by lane, without
+// that threshold, repeated the per-ray set-up at partial occupancy and was 1.8x slower on
+// primary rays).  Coherent camera rays do best in fixed chunks, the rays of later bounces
+// refilled.
 //
 // Rebuilt acceleration structure: workgroups of kExtendThreads threads; LDS holds, in this
 // order, the hottest nodes, the hottest instance records (both copied in by the workgroup

@@ -33,8 +33,8 @@ NOALLOC_MAX_DEPTH = 63
 
 EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
-    "rt_hip_render", "rt_hip_reserve", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
-    "rt_hip_probe", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
+    "rt_hip_render", "rt_hip_reserve", "rt_hip_tune", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
+    "rt_hip_probe", "rt_hip_triangle_never_hit", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes", "rt_hip_reduce",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
     "rt_hip_trace_work", "rt_hip_trace_refill", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
@@ -56,7 +56,7 @@ class TraceWork(C.Structure):
 
 PROBE_RAND01, PROBE_HASH_COMBINE, PROBE_RAND_UINT, PROBE_HIT_AABB, PROBE_HIT_TRIANGLE, \
     PROBE_EVAL_DISNEY, PROBE_SAMPLE_DISNEY, PROBE_SAMPLE_TEXTURE, PROBE_SKY, \
-    PROBE_SKY_SAMPLE = range(10)
+    PROBE_SKY_SAMPLE, PROBE_TRIANGLE_DEGENERATE = range(11)
 
 
 class ProbeIn(C.Structure):
@@ -94,6 +94,7 @@ def lib():
                                     u32p, C.c_void_p, C.c_void_p]
         l.rt_hip_render_noalloc.argtypes = l.rt_hip_render.argtypes
         l.rt_hip_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        l.rt_hip_tune.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_void_p]
         l.rt_hip_render_tile.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p]
         l.rt_hip_render_preview.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32,
@@ -102,6 +103,7 @@ def lib():
                                          fp, fp]
         l.rt_hip_probe.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(ProbeIn),
                                    C.POINTER(ProbeOut)]
+        l.rt_hip_triangle_never_hit.argtypes = [fp, C.c_uint32, u32p]
         l.rt_hip_read_accum.argtypes = [C.c_void_p, fp, u32p, C.c_void_p]
         l.rt_hip_read_preview.argtypes = [C.c_void_p, fp, C.c_void_p]
         l.rt_hip_accum_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
@@ -156,6 +158,11 @@ class HipRenderer:
     def reserve(self, width, height, pass_count):
         """Allocate the pipeline's path state for calls of that size now (rt_hip_reserve)."""
         _check(lib().rt_hip_reserve(self._h, width, height, pass_count))
+
+    def tune(self, camera, pass_count, stream=None):
+        """Settle the per-scene trace policies now (rt_hip_tune): two untimed-by-the-caller
+        calls of pass_count passes into a scratch image."""
+        _check(lib().rt_hip_tune(self._h, C.byref(camera), pass_count, stream))
 
     def render_noalloc(self, camera, first_pass, pass_count, rect=None, accum_dev=None,
                        stream=None):
@@ -272,6 +279,15 @@ class HipRenderer:
             self.close()
         except Exception:
             pass
+
+
+def triangle_never_hit(corners):
+    """rt_hip_triangle_never_hit for an [n, 9] float32 array of corners: [n] bool."""
+    corners = np.ascontiguousarray(corners, dtype=np.float32).reshape(-1, 9)
+    out = np.zeros(len(corners), dtype=np.uint32)
+    _check(lib().rt_hip_triangle_never_hit(corners.ctypes.data_as(fp), len(corners),
+                                           out.ctypes.data_as(u32p)))
+    return out != 0
 
 
 def reduce(renderers):

@@ -162,6 +162,77 @@ def test_hit_triangle_is_bit_exact(bare):
     assert hits > 1000
 
 
+def degenerate_cases():
+    """Triangles whose edge cross product is within a few ulp of the 1e-8 threshold of
+    hit_triangle's first test, from both sides: right-angled ones with legs p and q, p * q
+    stepped through the floats around 1e-8 (the length is then one product, one square, one
+    square root), the same in general position (all three components of the cross product
+    non-zero, so the sums round too), with tiny legs whose products are denormal, and slivers
+    of large triangles."""
+    rng = np.random.RandomState(5)
+    out = []
+    thr = np.float32(1e-8)
+    near = [thr]
+    lo = hi = thr
+    for _ in range(6):
+        lo, hi = np.nextafter(lo, np.float32(0)), np.nextafter(hi, np.float32(1))
+        near += [lo, hi]
+    for target in near:
+        for p in (1e-4, 3e-3, 1.0, 7.5e-7, 2e-12, 1e-20, 41.0):
+            p = np.float32(p)
+            q = np.float32(target / p)
+            for dq in range(-2, 3):
+                qq = q
+                for _ in range(abs(dq)):
+                    qq = np.nextafter(qq, np.float32(np.inf if dq > 0 else 0))
+                # axis-aligned right angle at a random corner
+                a = rng.uniform(-1, 1, size=3).astype(np.float32) * np.float32(rng.choice([0, 1, 100]))
+                b = a + np.float32([p, 0, 0])
+                c = a + np.float32([0, qq, 0])
+                out.append(np.concatenate([a, b, c]))
+                # the same legs along a random orthonormal pair
+                m = np.linalg.qr(rng.normal(size=(3, 3)))[0].astype(np.float32)
+                out.append(np.concatenate([a, a + m[0] * p, a + m[1] * qq]).astype(np.float32))
+    for _ in range(400):    # slivers: c almost on the line a b
+        a = rng.uniform(-50, 50, size=3).astype(np.float32)
+        e = rng.uniform(-1, 1, size=3).astype(np.float32)
+        b = a + e
+        s = np.float32(rng.uniform(0, 1))
+        c = a + e * s + rng.normal(size=3).astype(np.float32) * np.float32(10.0 ** rng.uniform(-10, -6))
+        out.append(np.concatenate([a, b, c]).astype(np.float32))
+    return np.stack(out).astype(np.float32)
+
+
+def test_hoisted_degenerate_triangle_test_agrees_with_the_device(bare):
+    """The rebuilt structure decides on the HOST which triangles can never be hit
+    (rt_hip_triangle_never_hit) and the walk then skips hit_triangle's first test; the host's
+    float arithmetic must therefore give the device's verdict on every triangle, also where the
+    cross product's length is an ulp from the threshold or its terms are denormal."""
+    cases = degenerate_cases()
+    host_says = hip.triangle_never_hit(cases)
+    u, _ = bare.probe(hip.PROBE_TRIANGLE_DEGENERATE, [([], list(t), None) for t in cases])
+    device_says = u[:, 0] != 0
+    assert (host_says == device_says).all(), np.nonzero(host_says != device_says)[0][:10]
+    # the cases straddle the threshold: both verdicts occur, among the ulp-close ones too
+    assert 0.2 < host_says.mean() < 0.8, host_says.mean()
+    # and the oracle's hit_triangle (the reference's arithmetic in C) rejects exactly those that
+    # a ray through the centroid, along the normal, would otherwise hit
+    checked = 0
+    for t, never in zip(cases[:200], host_says[:200]):
+        a, b, c = t.reshape(3, 3).astype(np.float64)
+        n = np.cross(b - a, c - a)
+        if not np.linalg.norm(n) > 0:
+            continue
+        n /= np.linalg.norm(n)
+        g = (a + b + c) / 3
+        o = (g + n).astype(np.float32)
+        hit, _ = oracle.hit_triangle(t, o, (-n).astype(np.float32), 0.0, INF)
+        if never:
+            assert not hit
+            checked += 1
+    assert checked > 10
+
+
 def test_texture_fetch_is_bit_exact(staircase, textured):
     rng = np.random.RandomState(4)
     for scene in (staircase, textured):

@@ -210,6 +210,29 @@ def test_image_parity_hyperion_depth7(hyperion, accel):
 
 
 @pytest.mark.parametrize("accel", ACCELS)
+def test_image_parity_cornell_depth7(cornell, accel):
+    """The baseline's first configuration (assets/cornell_box.json at max_depth 7): a closed box
+    in which a quarter of the paths run all eight bounces.  Fixed bars, identical ray counts up
+    to a few flipped branches."""
+    w, h, tile, spp, md = 320, 180, (64, 36), 8, 7
+    cam = cornell.camera(w, h)
+    seeds = host.seed_schedule(0, spp, 25)
+    want, ost = oracle.render(cornell.desc, cam, w, h, md, tile, seeds)
+    r = make_renderer(cornell, w, h, md, tile, accel)
+    r.upload_seeds(seeds)
+    r.clear()
+    r.render(cam, 0, spp)
+    got, _ = r.read_accum()
+    st = r.stats()
+    r.close()
+    assert_image_close(got, want, f"cornell depth 7 accel {accel}")
+    assert st["samples"] == ost["samples"] == w * h * spp
+    assert abs(st["closest_rays"] - ost["closest_rays"]) <= 16
+    assert abs(st["closest_hits"] - ost["closest_hits"]) <= 16
+    assert abs(st["shadow_rays"] + st["shadow_skipped"] - ost["shadow_rays"]) <= 16
+
+
+@pytest.mark.parametrize("accel", ACCELS)
 def test_image_parity_textures_and_environment_map(textured, accel):
     info = textured.info
     w, h, tile, md, spp = info.resolution_x, info.resolution_y, (40, 30), info.max_depth, 8

@@ -339,6 +339,58 @@ def test_reserve_then_render(cornell):
     assert same(img, plain[0])
 
 
+def test_tune_settles_the_policies_before_the_first_render(hyperion):
+    """rt_hip_tune makes the two measured calls itself, into a scratch image: afterwards both
+    policies are settled, accumulator and pass counter are untouched, and the first render is
+    the settled one - with the pixels of a render that was never tuned."""
+    w, h, md, tile, spp = 640, 800, 7, (64, 80), 16
+    plain = run(hyperion, w, h, md, tile, spp, hip.ACCEL_REBUILT, hip.FLAG_FUSED)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.upload_scene(hyperion.desc)
+        cam = hyperion.camera(w, h)
+        r.clear()
+        assert r.trace_refill()[0] == hip.REFILL_UNDECIDED
+        r.tune(cam, spp)                     # needs no seeds: it draws from a constant
+        state, off, on, mask = r.trace_refill()
+        assert state in (hip.REFILL_OFF, hip.REFILL_ON) and off > 0.0 and on > 0.0
+        assert r.ray_binning()[0] != hip.BINNING_UNDECIDED
+        img, passes = r.read_accum()
+        assert passes == 0 and not img[..., :3].any()
+        r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+        r.render(cam, 0, spp)
+        assert r.trace_refill() == (state, off, on, mask)   # nothing left to measure
+        img, passes = r.read_accum()
+    finally:
+        r.close()
+    assert passes == spp and same(img, plain[0])
+
+
+def test_refill_measurement_compares_calls_of_different_size_per_ray(hyperion):
+    """The two measured calls may differ in size: the verdict is taken per ray, and a call that
+    is not within a factor of two of the base line replaces it instead of being compared."""
+    w, h, md, tile = 640, 800, 7, (64, 80)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(host.seed_schedule(0, 128, r.tile_count))
+        cam = hyperion.camera(w, h)
+        r.clear()
+        r.render(cam, 0, 48)           # base line: 24.6 M paths
+        r.read_accum()
+        assert r.trace_refill()[0] == hip.REFILL_UNDECIDED and r.trace_refill()[1] > 0.0
+        r.render(cam, 48, 9)           # 4.6 M paths: too small to compare, the new base line
+        r.read_accum()
+        state, off_small, on, _ = r.trace_refill()
+        assert state == hip.REFILL_UNDECIDED and on < 0.0
+        r.render(cam, 57, 12)          # 6.1 M paths: compared with it, per ray
+        r.read_accum()
+        state, off, on, mask = r.trace_refill()
+        assert state in (hip.REFILL_OFF, hip.REFILL_ON) and off == off_small and on > 0.0
+    finally:
+        r.close()
+
+
 def test_calls_on_different_streams_of_one_handle_are_ordered(hyperion):
     """A handle's calls share its path state and counters.  Issued on two different streams
     back to back (no host synchronisation in between), the second must wait for the first on

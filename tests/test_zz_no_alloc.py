@@ -81,3 +81,64 @@ def test_noalloc_refuses_what_does_not_fit(cornell):
             r.render_noalloc(cornell.camera(160, 96), 0, 1)
     finally:
         r.close()
+
+
+def test_noalloc_allocates_no_device_memory(cornell):
+    """The property the entry point exists for: once the renderer is set up, a call takes no
+    device memory - the free bytes hipMemGetInfo reports are the same before and after, for
+    calls of different sizes."""
+    import torch
+    w, h, md, tile = 640, 360, 7, (64, 36)
+    r = hip.HipRenderer(w, h, md, tile)
+    try:
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, 4, r.tile_count))
+        cam = cornell.camera(w, h)
+        r.clear()
+        r.render_noalloc(cam, 0, 1, rect=(0, 0, 256, 256))   # warm: code objects, first launch
+        torch.cuda.synchronize()
+        free_before, _ = torch.cuda.mem_get_info()
+        r.render_noalloc(cam, 1, 2, rect=(64, 20, 576, 340))
+        r.render_noalloc(cam, 3, 1, rect=(101, 50, 304, 167))
+        torch.cuda.synchronize()
+        free_after, _ = torch.cuda.mem_get_info()
+        assert free_after == free_before, (free_before, free_after)
+        # the allocating entry point, for contrast, takes its path state on its first call
+        r.render(cam, 0, 1, rect=(0, 0, 256, 256))
+        torch.cuda.synchronize()
+        assert torch.cuda.mem_get_info()[0] < free_before
+    finally:
+        r.close()
+
+
+def test_noalloc_recorded_into_a_hip_graph(cornell):
+    """One call captured on a stream and replayed as a graph gives the pixels of rt_hip_render:
+    nothing in the call allocates, synchronises or waits on events from outside the capture."""
+    import torch
+    w, h, md, tile = 640, 360, 5, (64, 36)
+    rect = (64, 20, 576, 340)
+    r = hip.HipRenderer(w, h, md, tile)
+    try:
+        r.upload_scene(cornell.desc)
+        r.upload_seeds(host.seed_schedule(0, 2, r.tile_count))
+        cam = cornell.camera(w, h)
+        r.clear()
+        r.render(cam, 0, 2, rect=rect)
+        want, _ = r.read_accum()
+        r.clear()
+        r.render_noalloc(cam, 0, 1, rect=(0, 0, 64, 64))  # warm outside the capture
+        r.clear()
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            r.render_noalloc(cam, 0, 2, rect=rect,
+                             stream=torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        empty, _ = r.read_accum()
+        assert not empty[..., :3].any()      # capturing ran nothing
+        graph.replay()
+        torch.cuda.synchronize()
+        got, _ = r.read_accum()
+        assert same(got, want)
+    finally:
+        r.close()
