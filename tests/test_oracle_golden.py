@@ -198,3 +198,58 @@ def test_oracle_matches_the_reference_screenshot_in_linear_radiance(hyperion):
     rel = np.abs(a - b).sum(axis=2) / (b.sum(axis=2) + 1e-3)
     assert np.median(rel[dark]) < 0.03, np.median(rel[dark])
     assert np.percentile(rel[dark], 90) < 0.12
+
+
+def converged_fixture():
+    z = np.load(os.path.join(GOLDEN, "oracle_hyperion_converged.npz"))
+    w, h, md, passes, dx, dy = (int(v) for v in z["params"])
+    return z, w, h, md, passes, dx, dy
+
+
+def test_converged_oracle_render_matches_the_reference_screenshot(hyperion):
+    """The tight pin of the oracle on the reference's own output.  The fixture holds the block
+    means, object colours and picture mean of the ORACLE's render of hyperion_rect_light as
+    shipped at 1024 passes (tools/make_converged_fixture.py, made in the build container); they
+    are held to the reference's window capture with the bars of the HIP path's own comparison
+    (tests/test_gpu_reference_screenshots.py): block means within 1e-3 on average, 5e-3 at the
+    99th percentile, 1e-2 at most (one 8-bit step of the capture is 3.9e-3), objects within
+    4e-3, the whole picture within 1e-3 per channel."""
+    import screenshots as S
+    z, w, h, md, passes, dx, dy = converged_fixture()
+    assert (w, h, md, passes) == (1280, 720, 5, 1024) and (dx, dy) == (3, 4)
+    shot = S.load_screenshot("hyperion_rect_light")
+    err = np.abs(z["display_blocks"] - S.block_means(shot))
+    assert err.shape[:2] == (22, 39)
+    assert err.mean() < 1.0e-3, err.mean()
+    assert np.percentile(err, 99) < 5.0e-3, np.percentile(err, 99)
+    assert err.max() < 1.0e-2, err.max()
+    assert (np.abs(z["whole_display"] - shot.mean(axis=(0, 1))) < 1.0e-3).all()
+    tile = (hyperion.info.tile_width, hyperion.info.tile_height)
+    ids = oracle.primary_ids(hyperion.desc, hyperion.camera(w, h), w, h, tile,
+                             host.seed_schedule(0, 1, (w // tile[0]) * (h // tile[1])))[0]
+    sh, sw, _ = shot.shape
+    theirs = S.object_colours(shot, ids[dy:dy + sh, dx:dx + sw], 2000)
+    assert sorted(theirs) == [int(i) for i in z["object_ids"]] and len(theirs) >= 20
+    for i, mine in zip(z["object_ids"], z["object_display"]):
+        assert np.abs(mine - theirs[int(i)]).max() < 4.0e-3, (i, mine, theirs[int(i)])
+
+
+def test_oracle_reproduces_a_strip_of_the_converged_fixture(hyperion):
+    """The fixture cannot drift from the code: the oracle as it is now re-renders a 320 x 8
+    pixel strip of that 1024-pass image and must reproduce the stored accumulator (bit for bit
+    with the math library the fixture was made with; a last-place difference in a
+    transcendental may flip a few paths with another one)."""
+    z, w, h, md, passes, _, _ = converged_fixture()
+    x0, y0, x1, y1 = (int(v) for v in z["strip_rect"])
+    tile = (hyperion.info.tile_width, hyperion.info.tile_height)
+    tiles = (w // tile[0]) * (h // tile[1])
+    cam = hyperion.camera(w, h)
+    accum = None
+    for first in range(0, passes, 64):
+        accum, _ = oracle.render(hyperion.desc, cam, w, h, md, tile,
+                                 host.seed_schedule(first, 64, tiles), accum=accum,
+                                 first_pass=first, rect=(x0, y0, x1, y1))
+    got, want = accum[y0:y1, x0:x1, :3], z["strip_accum"][..., :3]
+    close = np.abs(got - want) <= 1e-5 * np.abs(want) + 1e-6
+    assert close.mean() > 0.999, close.mean()
+    assert abs(got.sum() / want.sum() - 1.0) < 1e-4
