@@ -152,6 +152,14 @@ int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pa
  * the reference, whose images and buffers are all created in prepare_data (:269-467). */
 int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t pass_count);
 
+/* (diagnostics, no counterpart) What the uploaded scene's materials and lights can make the
+ * shading code do - bit 0: a material with spec_trans != 0 (glass lobe), 1: clearcoat != 0,
+ * 2: metallic != 0 or a metallic-roughness texture, 3: any texture on a material or light,
+ * 4: a sky light - and the feature set of the pipeline's shading kernels chosen for it (the
+ * smallest compiled set that covers those bits; code a scene cannot reach is compiled out,
+ * which cannot change a result). */
+int rt_hip_shade_features(rt_hip_renderer* r, uint32_t* scene_features, uint32_t* kernel_features);
+
 /* Optional: settles, before the first render that counts, what rt_hip_render otherwise
  * measures on its first two large calls (at least 2^22 paths each) after every scene upload:
  * per bounce, whether the trace launch hands out rays in fixed chunks or refills finished

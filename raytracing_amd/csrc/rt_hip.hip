@@ -24,8 +24,19 @@
 
 using namespace rtd;
 
-#ifndef RT_EXP_F
-#define RT_EXP_F kShadeAll
+// The shading kernels of the pipeline, one instantiation per feature set: each set is compiled
+// in its own translation unit (shade_variant.hip).  RT_EXP_F (diagnostic builds, e.g. with
+// RT_SHADE_REGION_TIMING, whose cycle counters are per translation unit): one set only, compiled
+// here, used for every scene.
+#ifdef RT_EXP_F
+template void rtd::launch_shade_stage<(uint32_t) (RT_EXP_F)>(wavefront_params const&, uint32_t,
+    dim3, dim3, uint32_t, hipStream_t);
+#else
+#define RT_EXTERN_SHADE(F)                                                                    \
+    extern template void rtd::launch_shade_stage<F>(wavefront_params const&, uint32_t, dim3,  \
+        dim3, uint32_t, hipStream_t);
+RT_SHADE_VARIANTS(RT_EXTERN_SHADE)
+#undef RT_EXTERN_SHADE
 #endif
 
 // ---------------------------------------------------------------------------
@@ -427,6 +438,9 @@ struct rt_hip_renderer {
     scene_dev sc{};
     bool scene_ready = false;
     uint64_t accel_node_bytes = 0, accel_tri_bytes = 0, accel_instance_bytes = 0;  // as traversed
+    // what the scene's materials and lights can make the shading code do (kFeat* bits) and the
+    // compiled feature set of the pipeline's shading kernels chosen for it
+    uint32_t shade_features = kShadeAll, shade_variant = kShadeAll;
 
     uint32_t* seeds = nullptr;
     size_t seeds_capacity = 0;
@@ -646,6 +660,42 @@ void validate_scene(rt_scene_desc const& s) {
                  s.textures[i].format <= RT_TEX_F32X4,
             "texture");
     }
+}
+
+// What the scene's materials and lights can make the shading code do (rt_shading.h: kFeat*).
+// A feature the scene cannot use is compiled out of the pipeline's shading kernels; every test
+// here is on the uploaded values themselves, so no path of the scene can reach removed code.
+uint32_t scene_features(rt_scene_desc const& s, uint32_t flags) {
+    uint32_t f = 0;
+    for (uint32_t i = 0; i < s.material_count; ++i) {
+        rt_material const& m = s.materials[i];
+        // (anything but an exact zero counts, NaN included)
+        if (!(m.spec_trans == 0.0f)) {
+            f |= kFeatGlass;
+        }
+        if (!(m.clearcoat == 0.0f)) {
+            f |= kFeatClearcoat;
+        }
+        if (!(m.metallic == 0.0f) || m.metallic_roughness_tex >= 0) {
+            f |= kFeatMetal;
+        }
+        if (m.albedo_tex >= 0 || m.emission_tex >= 0 || m.normal_tex >= 0 ||
+            m.metallic_roughness_tex >= 0) {
+            f |= kFeatTextures;
+        }
+    }
+    for (uint32_t i = 0; i < s.light_count; ++i) {
+        if (s.lights[i].emission_tex >= 0) {
+            f |= kFeatTextures;
+        }
+        if (s.lights[i].type == RT_LIGHT_SKY) {
+            f |= kFeatSky;
+        }
+    }
+    if (s.sky_light >= 0) {
+        f |= kFeatSky;
+    }
+    return f;
 }
 
 // Tables for the opt-in importance sampling of the environment map (rt_shading.h:
@@ -1281,17 +1331,21 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                 r.end_timing(t, stream);
                 t = r.begin_timing(stream, RT_HIP_KERNEL_SHADE);
             }
-            if (trip == 0u) {
-                hipLaunchKernelGGL((wf_settle_kernel<true, RT_EXP_F>), settle_grid,
-                    dim3(kSettleThreads), shade_lds, stream, w, trip);
-                hipLaunchKernelGGL((wf_shade_kernel<true, RT_EXP_F>), shade_grid, dim3(kShadeThreads),
-                    shade_lds, stream, w, trip);
-            } else {
-                hipLaunchKernelGGL((wf_settle_kernel<false, RT_EXP_F>), settle_grid,
-                    dim3(kSettleThreads), shade_lds, stream, w, trip);
-                hipLaunchKernelGGL((wf_shade_kernel<false, RT_EXP_F>), shade_grid, dim3(kShadeThreads),
-                    shade_lds, stream, w, trip);
+#ifdef RT_EXP_F
+            launch_shade_stage<(uint32_t) (RT_EXP_F)>(w, trip, settle_grid, shade_grid, shade_lds,
+                stream);
+#else
+            switch (r.shade_variant) {
+#define RT_LAUNCH_SHADE(F)                                                                 \
+    case F:                                                                                \
+        launch_shade_stage<F>(w, trip, settle_grid, shade_grid, shade_lds, stream);        \
+        break;
+                RT_SHADE_VARIANTS(RT_LAUNCH_SHADE)
+#undef RT_LAUNCH_SHADE
+            default:
+                throw std::logic_error("no shading kernels for the scene's feature set");
             }
+#endif
             HIP_CHECK(hipGetLastError());
             if (each) {
                 r.end_timing(t, stream);
@@ -1788,6 +1842,14 @@ int rt_hip_upload_scene(rt_hip_renderer* r, const rt_scene_desc* scene) {
         d.textures = r->upload(textures.data(), textures.size());
         d.light_count = s.light_count;
         d.sky_light = s.sky_light;
+        r->shade_features = scene_features(s, r->cfg.flags);
+        r->shade_variant = shade_variant_for(r->shade_features);
+        if (char const* const v = getenv("RT_HIP_SHADE_FEATURES")) {  // experiments: a superset
+            uint32_t const forced = (uint32_t) atoi(v) & kShadeAll;
+            if ((r->shade_features & ~forced) == 0u) {
+                r->shade_variant = shade_variant_for(forced);
+            }
+        }
         d.instance_count = s.instance_count;
         d.transform_count = s.transform_count;
         d.material_count = s.material_count;
@@ -1964,6 +2026,22 @@ int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t
         device_scope const on_device(r->device);
         bool const binned = r->binning != RT_HIP_BINNING_OFF;  // decided later: be ready for it
         ensure_wavefront(*r, per_pass * batch, r->cfg.max_depth + 1u, binned);
+    });
+}
+
+int rt_hip_shade_features(rt_hip_renderer* r, uint32_t* scene_features, uint32_t* kernel_features) {
+    return guarded([&] {
+        require_scene(r);
+        if (scene_features) {
+            *scene_features = r->shade_features;
+        }
+        if (kernel_features) {
+#ifdef RT_EXP_F
+            *kernel_features = (uint32_t) (RT_EXP_F);
+#else
+            *kernel_features = r->shade_variant;
+#endif
+        }
     });
 }
 

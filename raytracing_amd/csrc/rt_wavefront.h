@@ -264,6 +264,7 @@ RT_DEV triple block_inclusive_scan(triple v, uint32_t (*scratch)[THREADS]) {
     return triple{scratch[0][t], scratch[1][t], scratch[2][t]};
 }
 
+#ifndef RT_SHADE_VARIANT_TU  // (a translation unit that only instantiates shading kernels)
 // (1) also counts the raw slots, 64 at a time, and leaves the packed counts in chunk_counts:
 // the producers write raw words only, in any order and from several launches.
 __global__ void __launch_bounds__(kTileThreads) wf_tile_sums_kernel(wavefront_params const p,
@@ -571,6 +572,8 @@ __global__ void __launch_bounds__(kBinThreads) wf_bin_place_kernel(wavefront_par
         }
     }
 }
+
+#endif  // RT_SHADE_VARIANT_TU
 
 // Traces every ray of trip `trip`: first the closest-hit queue, then the occlusion queue, so
 // a wave never mixes the two kinds.  Two ways of handing the rays to the lanes, chosen per
@@ -1225,6 +1228,47 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
     }
 }
 
+// The two launches of one shading stage for feature set F (host side).
+template <uint32_t F>
+void launch_shade_stage(wavefront_params const& w, uint32_t trip, dim3 settle_grid,
+    dim3 shade_grid, uint32_t lds_bytes, hipStream_t stream) {
+    if (trip == 0u) {
+        hipLaunchKernelGGL((wf_settle_kernel<true, F>), settle_grid, dim3(kSettleThreads),
+            lds_bytes, stream, w, trip);
+        hipLaunchKernelGGL((wf_shade_kernel<true, F>), shade_grid, dim3(kShadeThreads), lds_bytes,
+            stream, w, trip);
+    } else {
+        hipLaunchKernelGGL((wf_settle_kernel<false, F>), settle_grid, dim3(kSettleThreads),
+            lds_bytes, stream, w, trip);
+        hipLaunchKernelGGL((wf_shade_kernel<false, F>), shade_grid, dim3(kShadeThreads), lds_bytes,
+            stream, w, trip);
+    }
+}
+
+// The feature sets the shading kernels are compiled for (rt_shading.h: kFeat*), each in a
+// translation unit of its own (shade_variant.hip) so that they build side by side; a scene gets
+// the smallest one that covers what its materials and lights can do (shade_variant_for).
+//    0  diffuse / dielectric surfaces, area lights (the Cornell box)
+//    7  + glass, clearcoat, metal (hyperion_rect_light)
+//   13  glass, metal, textures (the staircase)
+//   23  glass, clearcoat, metal under a constant sky (the generated 10 000-instance scene)
+//   24  textures and an environment map (the teapot file)
+//   31  everything
+#define RT_SHADE_VARIANTS(X) X(0u) X(7u) X(13u) X(23u) X(24u) X(31u)
+
+inline uint32_t shade_variant_for(uint32_t features) {
+    uint32_t best = kShadeAll;
+    uint32_t best_bits = 32u;
+#define RT_CONSIDER(F)                                                                  \
+    if ((features & ~(F)) == 0u && (uint32_t) __builtin_popcount(F) < best_bits) {      \
+        best = (F);                                                                     \
+        best_bits = (uint32_t) __builtin_popcount(F);                                   \
+    }
+    RT_SHADE_VARIANTS(RT_CONSIDER)
+#undef RT_CONSIDER
+    return best;
+}
+
 // Runs every path handed over at trip `trip` (kCtlFinish, see wf_scan_tiles_kernel) to its
 // end inside one kernel, fused-kernel style (trace, shade, trace ... with the path in
 // registers).  Once few paths are left, giving each of their remaining bounces a trace
@@ -1321,6 +1365,7 @@ __global__ void __launch_bounds__(64, 2) wf_finish_kernel(wavefront_params const
     }
 }
 
+#ifndef RT_SHADE_VARIANT_TU
 // Adds the batch's finished paths to the frame, pass by pass
 // (megakernel_raytracer.comp:108-113 once per pass, in pass order).
 __global__ void __launch_bounds__(256) wf_resolve_kernel(wavefront_params const p) {
@@ -1343,5 +1388,7 @@ __global__ void __launch_bounds__(256) wf_resolve_kernel(wavefront_params const 
     }
     *reinterpret_cast<float4*>(px) = make_float4(acc.x, acc.y, acc.z, 1.0f);
 }
+
+#endif  // RT_SHADE_VARIANT_TU
 
 }  // namespace rtd

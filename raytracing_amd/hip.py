@@ -33,7 +33,7 @@ NOALLOC_MAX_DEPTH = 63
 
 EXPORTS = [
     "rt_hip_create", "rt_hip_upload_scene", "rt_hip_upload_seeds", "rt_hip_clear",
-    "rt_hip_render", "rt_hip_reserve", "rt_hip_tune", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
+    "rt_hip_render", "rt_hip_reserve", "rt_hip_tune", "rt_hip_shade_features", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_probe", "rt_hip_triangle_never_hit", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes", "rt_hip_reduce",
     "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
@@ -71,6 +71,32 @@ fp = C.POINTER(C.c_float)
 u32p = C.POINTER(C.c_uint32)
 
 
+class _Missing:
+    """Stands for a symbol that an older build of the library (RT_HIP_LIB, A/B runs) lacks."""
+
+    def __init__(self, name):
+        self.name = name
+        self.argtypes = self.restype = None
+
+    def __call__(self, *args):
+        raise RuntimeError(f"{_LIB_PATH} does not export {self.name}")
+
+
+class _Bound:
+    """The loaded library; with `tolerant`, a missing symbol fails when called, not when bound."""
+
+    def __init__(self, dll, tolerant):
+        self._dll, self._tolerant, self._missing = dll, tolerant, {}
+
+    def __getattr__(self, name):
+        try:
+            return getattr(self._dll, name)
+        except AttributeError:
+            if not self._tolerant:
+                raise
+            return self._missing.setdefault(name, _Missing(name))
+
+
 def lib():
     global _lib
     if _lib is None:
@@ -85,6 +111,7 @@ def lib():
         except ImportError:
             pass
         l = C.CDLL(_LIB_PATH)
+        l = _Bound(l, tolerant=bool(os.environ.get("RT_HIP_LIB")))
         l.rt_hip_last_error.restype = C.c_char_p
         l.rt_hip_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
         l.rt_hip_upload_scene.argtypes = [C.c_void_p, C.POINTER(T.SceneDesc)]
@@ -94,6 +121,7 @@ def lib():
                                     u32p, C.c_void_p, C.c_void_p]
         l.rt_hip_render_noalloc.argtypes = l.rt_hip_render.argtypes
         l.rt_hip_reserve.argtypes = [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint32]
+        l.rt_hip_shade_features.argtypes = [C.c_void_p, u32p, u32p]
         l.rt_hip_tune.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_void_p]
         l.rt_hip_render_tile.argtypes = [C.c_void_p, C.POINTER(T.Camera), C.c_uint32, C.c_uint32,
                                          C.c_uint32, C.c_void_p]
@@ -158,6 +186,12 @@ class HipRenderer:
     def reserve(self, width, height, pass_count):
         """Allocate the pipeline's path state for calls of that size now (rt_hip_reserve)."""
         _check(lib().rt_hip_reserve(self._h, width, height, pass_count))
+
+    def shade_features(self):
+        """(feature bits of the uploaded scene, feature set of the shading kernels chosen)."""
+        scene, kernel = C.c_uint32(), C.c_uint32()
+        _check(lib().rt_hip_shade_features(self._h, C.byref(scene), C.byref(kernel)))
+        return scene.value, kernel.value
 
     def tune(self, camera, pass_count, stream=None):
         """Settle the per-scene trace policies now (rt_hip_tune): two untimed-by-the-caller

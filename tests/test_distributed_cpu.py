@@ -184,3 +184,88 @@ def test_reduce_is_identity_without_a_process_group():
     accum[..., :3] = 2.0
     out = rd.reduce_accumulator(accum)
     assert out is accum and (accum[..., :3] == 2.0).all() and (accum[..., 3] == 1.0).all()
+
+
+def _bench_module():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def _schedule(bench, world, rank, steps, warmup, total_spp, spp=8):
+    args = bench.parse_args(["--spp-per-step", str(spp)] +
+                            (["--total-spp", str(total_spp)] if total_spp else []))
+    return bench.call_schedule(bench.Workload(args), world, rank, steps, warmup)
+
+
+def test_bench_strong_scaling_schedule_covers_every_pass_once():
+    """bench.py --total-spp S: in every step the ranks' render calls together cover the global
+    passes [s * S, (s + 1) * S) exactly once, in calls of at most --spp-per-step passes; the
+    set-up calls use passes of their own."""
+    bench = _bench_module()
+    steps, warmup = 3, 1
+    for world in (1, 2, 3, 8):
+        for total in (5, 64, 100):
+            seen = {}
+            for rank in range(world):
+                calls, starts = _schedule(bench, world, rank, steps, warmup, total)
+                assert len(starts) == bench.SETUP_CALLS + warmup + steps
+                bounds = starts + [len(calls)]
+                for s in range(len(starts)):
+                    for first, count in calls[bounds[s]:bounds[s + 1]]:
+                        assert 1 <= count <= 8
+                        for p in range(first, first + count):
+                            assert p not in seen, (world, total, rank, p)
+                            seen[p] = (s, rank)
+            for s in range(warmup + steps):
+                step = [p for p, (k, _) in seen.items() if k == bench.SETUP_CALLS + s]
+                assert sorted(step) == list(range(s * total, (s + 1) * total))
+            # set-up passes lie beyond every step's
+            setup = [p for p, (k, _) in seen.items() if k < bench.SETUP_CALLS]
+            assert min(setup) >= (warmup + steps) * total
+    # weak scaling: every rank the same number of passes, ranges disjoint
+    owned = [set() for _ in range(4)]
+    for rank in range(4):
+        calls, _ = _schedule(bench, 4, rank, steps, warmup, None)
+        assert [c for _, c in calls] == [8] * (bench.SETUP_CALLS + warmup + steps)
+        for first, count in calls:
+            owned[rank] |= set(range(first, first + count))
+    assert all(not (owned[a] & owned[b]) for a in range(4) for b in range(a))
+
+
+def _bench_rank(rank, world, port, total_spp, out_dir):
+    """A bench.py rank with a stub in place of the renderer: a "render" of pass p adds p + 1 to
+    the rank's accumulator; the schedule and the reduce are the bench's own."""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    steps, warmup = 2, 1
+    calls, starts = _schedule(bench, world, rank, steps, warmup, total_spp)
+    bounds = starts + [len(calls)]
+    accum = rd.new_accumulator(2, 2, "cpu")
+    mine = []
+    for s in range(bench.SETUP_CALLS + warmup, bench.SETUP_CALLS + warmup + steps):
+        for first, count in calls[bounds[s]:bounds[s + 1]]:
+            for p in range(first, first + count):
+                accum[..., :3] += float(p + 1)
+                mine.append(p)
+    rd.reduce_accumulator(accum, dst=0)
+    np.save(os.path.join(out_dir, f"passes_{rank}.npy"), np.array(mine, dtype=np.int64))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "sum.npy"), accum.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_bench_ranks_share_the_passes_of_every_step(tmp_path):
+    total = 37
+    mp.spawn(_bench_rank, args=(2, _free_port(), total, str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / f"passes_{r}.npy") for r in range(2))
+    assert not set(a) & set(b)
+    # the two timed steps follow one warm-up step
+    assert sorted(list(a) + list(b)) == list(range(total, 3 * total))
+    reduced = np.load(tmp_path / "sum.npy")
+    want = sum(p + 1 for p in range(total, 3 * total))
+    assert (reduced[..., :3] == want).all() and (reduced[..., 3] == 1.0).all()

@@ -339,6 +339,40 @@ def test_reserve_then_render(cornell):
     assert same(img, plain[0])
 
 
+def test_shading_kernels_are_chosen_by_what_the_scene_can_do(request, monkeypatch):
+    """The pipeline's shading kernels exist once per feature set; a scene gets the smallest set
+    that covers its materials and lights.  Code compiled out is code no path of the scene can
+    reach, so the image equals the one of the kernels with everything in (forced through the
+    environment) bit for bit - and the fused kernel's, which always carries everything
+    (test_pipeline_equals_fused_kernel)."""
+    expect = {"cornell": (0, 0), "hyperion": (7, 7), "staircase": (13, 13), "mustang": (31, 31),
+              "teapot": (24, 24), "instanced": (23, 23), "textured": (28, 31)}
+    w, h, md, tile, spp = 320, 184, 6, (64, 46), 3
+    for name, want in expect.items():
+        scene = request.getfixturevalue(name)
+        images = []
+        for forced in (None, "31"):
+            if forced:
+                monkeypatch.setenv("RT_HIP_SHADE_FEATURES", forced)
+            else:
+                monkeypatch.delenv("RT_HIP_SHADE_FEATURES", raising=False)
+            r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+            try:
+                r.upload_scene(scene.desc)
+                got = r.shade_features()
+                if name != "instanced" and name != "textured":
+                    assert got == (want if not forced else (want[0], 31)), (name, got)
+                else:
+                    assert got[1] == (31 if forced else got[1]) and (got[0] & ~got[1]) == 0
+                r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+                r.clear()
+                r.render(scene.camera(w, h), 0, spp)
+                images.append(r.read_accum()[0])
+            finally:
+                r.close()
+        assert same(images[0], images[1]), name
+
+
 def test_tune_settles_the_policies_before_the_first_render(hyperion):
     """rt_hip_tune makes the two measured calls itself, into a scratch image: afterwards both
     policies are settled, accumulator and pass counter are untouched, and the first render is
