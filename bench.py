@@ -4,7 +4,8 @@
     python bench.py --gpus N --steps K --warmup W [--scene NAME] [--total-spp S]
 
 One step = one rt_hip_render call over the whole frame at max_depth 7, tracing --spp-per-step
-passes of every pixel (scene, seeds and accumulator already resident in HBM).  The reported
+passes of every pixel (scene, seeds and accumulator already resident in HBM; default 128 passes,
+which the library traces as two batches of 64 side by side on two streams).  The reported
 value is pixel-samples per second over all GPUs, in Msamples/s; Mrays/s comes from the device
 ray counters of the same timed region.
 
@@ -66,8 +67,9 @@ REF_NODE_BYTES = 32
 REF_TRI_BYTES = 36
 
 DEFAULT_SCENE = "hyperion_rect_light"
+DEFAULT_SPP = 128       # per render call: two batches of 64 passes = 59 M paths each
 DEFAULTS = {  # scene -> (width, height, spp per step)
-    "synthetic_4k": (3840, 2160, 8),   # 8 passes = 66.4 M paths, one batch of the pipeline
+    "synthetic_4k": (3840, 2160, 16),  # two batches of 8 passes = 66.4 M paths each
 }
 # the other configurations of the baseline: (scene, seconds of CPU baseline)
 OTHER_SCENES = (("mustang_red_reduced", 6.0), ("cornell_box", 3.0), ("staircase_reduced", 3.0),
@@ -85,9 +87,9 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--max-depth", type=int, default=7)
     ap.add_argument("--spp-per-step", type=int, default=None,
-                    help="passes per render call = one batch of the pipeline (default 64: 59 M "
-                         "paths, 8.3 GB of path state at 1280x720; 16 per call is 14 %% slower "
-                         "per sample)")
+                    help="passes per render call (default 128 = two batches of 64 passes in "
+                         "flight side by side: 2 x 59 M paths, 16.5 GB of path state at 1280x720; "
+                         "64 per call is 9 %% slower per sample, 16 per call 30 %%)")
     ap.add_argument("--total-spp", type=int, default=None,
                     help="strong scaling: one step = this many passes of the frame in all, "
                          "shared by the ranks (pass_range); default: --spp-per-step passes per "
@@ -108,7 +110,7 @@ def parse_args(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=15.0,
                     help="target duration of the CPU baseline sample")
     args = ap.parse_args(argv)
-    width, height, spp = DEFAULTS.get(args.scene, (1280, 720, 64))
+    width, height, spp = DEFAULTS.get(args.scene, (1280, 720, DEFAULT_SPP))
     args.width = args.width or width
     args.height = args.height or height
     args.spp_per_step = args.spp_per_step or spp
@@ -273,7 +275,8 @@ class Workload:
         if scene is None:
             self.width, self.height, self.spp_per_step = args.width, args.height, args.spp_per_step
         else:
-            self.width, self.height, self.spp_per_step = DEFAULTS.get(scene, (1280, 720, 64))
+            self.width, self.height, self.spp_per_step = DEFAULTS.get(scene,
+                                                                      (1280, 720, DEFAULT_SPP))
         self.max_depth = args.max_depth
         self.accel, self.pipeline = args.accel, args.pipeline
         self.binning, self.refill = args.binning, args.refill
@@ -375,6 +378,10 @@ def measure(env, w, steps, warmup, work_counters):
         if w.pipeline != "fused":
             m["extend_ms"], m["extend_n"] = r.kernel_time(hip.KERNEL_EXTEND)
             m["shade_ms"], m["shade_n"] = r.kernel_time(hip.KERNEL_SHADE)
+            # two batches of a call run side by side, so launches of one kind overlap: the time
+            # during which at least one of them ran
+            m["extend_busy_ms"] = r.kernel_busy(hip.KERNEL_EXTEND)
+            m["shade_busy_ms"] = r.kernel_busy(hip.KERNEL_SHADE)
     r.close()
     del accum
     if env.rank == 0 and work_counters and m["render_calls"] > 0:
@@ -429,11 +436,15 @@ def roofline_of(w, m):
     extra = {}
     if w.pipeline == "fused":
         name, ms, n = "path_trace_kernel", m["render_ms"], m["render_calls"]
+        ms_wall = ms
         closest_l, shadow_l = cst["closest_rays"], cst["shadow_rays"]
         nodes_l, tris_l = work["nodes"], work["tris"]
         launches_per_call = 1
     else:
-        name, ms, n = "wf_extend_kernel", m["extend_ms"], m["extend_n"]
+        name, ms_wall, n = "wf_extend_kernel", m["extend_ms"], m["extend_n"]
+        # net of overlap: the time during which at least one trace launch ran / launches
+        ms = m["extend_busy_ms"] / max(n, 1)
+        shade_net = m["shade_busy_ms"] / max(m["shade_n"], 1)
         per_call = n // calls
         refill = m["refill"]
         extra = {"ray_binning": ["undecided", "off", "on"][m["binning_state"]],
@@ -443,9 +454,12 @@ def roofline_of(w, m):
                  "trace_refill_bounces": f"{refill[3]:#x}",
                  "trace_launches_per_call": per_call,
                  "render_call_avg_ms": m["render_ms"], "render_calls": m["render_calls"],
-                 "shade_kernel_avg_ms": m["shade_ms"], "shade_launches": m["shade_n"],
-                 "extend_ms_per_call": ms * n / calls,
-                 "shade_ms_per_call": m["shade_ms"] * m["shade_n"] / calls}
+                 "shade_kernel_avg_ms": shade_net,
+                 "shade_kernel_avg_ms_wall": m["shade_ms"], "shade_launches": m["shade_n"],
+                 "extend_ms_per_call": m["extend_busy_ms"] / calls,
+                 "shade_ms_per_call": m["shade_busy_ms"] / calls,
+                 "extend_ms_per_call_sum_of_launches": ms_wall * n / calls,
+                 "shade_ms_per_call_sum_of_launches": m["shade_ms"] * m["shade_n"] / calls}
         # the trace launches of one call: every bounce that was not handed to the finishing
         # kernel (whose own fetches are subtracted); launches of later bounces return at once
         # and still count as launches, as rocprofv3 counts them
@@ -483,7 +497,13 @@ def roofline_of(w, m):
         "bound": bound,
         "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
         "traffic": traffic,
-        "kernel": name, "kernel_avg_ms": ms, "launches": n,
+        "kernel": name, "kernel_avg_ms": ms, "kernel_avg_ms_wall": ms_wall, "launches": n,
+        "kernel_avg_ms_definition": "two batches of a render call are in flight side by side, "
+                                    "so two trace launches often share the GPU: kernel_avg_ms = "
+                                    "(time during which at least one trace launch was running) / "
+                                    "launches, from the HIP events of every timed launch; "
+                                    "kernel_avg_ms_wall = the launches' own start-to-end times "
+                                    "averaged, which is what rocprofv3 --stats reports",
         "algorithmic_bytes_per_launch": bytes_l,
         "algorithmic_bytes_per_launch_served_by_memory": memory_bytes_l,
         "algorithmic_bytes_per_launch_served_by_lds": lds_bytes_l,
@@ -558,7 +578,7 @@ def shade_block(m, per_bounce, measured, calls):
     if "wf_shade_kernel" in per_launch:
         traffic = (per_launch["wf_shade_kernel"] + per_launch.get("wf_settle_kernel", 0.0)) \
             * launches_per_call
-    ms_call = m["shade_ms"] * m["shade_n"] / max(calls, 1)
+    ms_call = m["shade_busy_ms"] / max(calls, 1)
     issue = measured.get("issue") or {}
     return {
         "kernels": ["wf_settle_kernel", "wf_shade_kernel"],

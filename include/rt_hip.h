@@ -140,7 +140,13 @@ int rt_hip_clear(rt_hip_renderer* r, float* accum_dev, void* stream);
  * accumulator in pass order, exactly as that many sequential dispatches
  * would.  Seeds must have been uploaded for those passes.  Asynchronous on
  * `stream` (a hipStream_t; NULL = the default stream).
- * accum_dev: W*H*4 floats on the device, or NULL for the renderer's own. */
+ * accum_dev: W*H*4 floats on the device, or NULL for the renderer's own.
+ * A call of at least 2^24 paths (pixels x passes) is traced as two or more batches of
+ * passes, two of them in flight at a time: one on `stream`, the other on a stream of the
+ * renderer's own that starts after everything queued on `stream` before the call and that
+ * `stream` waits for before the call's work counts as done - towards the caller the call
+ * behaves like any other work queued on `stream`.  The second batch fills the GPU while the
+ * first one's late bounces (few paths, dependent launches) leave it mostly idle. */
 int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pass,
     uint32_t pass_count, const uint32_t* rect, float* accum_dev, void* stream);
 
@@ -313,7 +319,15 @@ int rt_hip_kernel_time(rt_hip_renderer* r, double* avg_ms, uint32_t* launches);
 int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
     uint32_t* launches);
 
-/* Diagnostics of the pipeline: in the most recent batch of passes, how many paths were
+/* A render call of two or more batches of passes runs two batches at a time, side by side on
+ * two streams (rt_hip_render), so launches of one kind overlap and their durations add up to
+ * more than the time the GPU spent on them.  busy_ms = the time, since the last reset of the
+ * statistics, during which AT LEAST ONE launch of that kind was running (the union of the
+ * launches' intervals).  Needs RT_HIP_FLAG_TIME_KERNELS for the per-launch kinds. */
+int rt_hip_kernel_busy_of(rt_hip_renderer* r, uint32_t kernel, double* busy_ms);
+
+/* Diagnostics of the pipeline: in the most recent batch of passes - in the most recent TWO,
+ * added up, when the last render call ran its batches two at a time - how many paths were
  * alive in bounce `trip` (counts[0]) and how many closest-hit (counts[1]) and occlusion
  * (counts[2]) rays it traced.  Synchronises the device.  No counterpart in the reference. */
 int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts);

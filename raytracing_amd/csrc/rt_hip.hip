@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types and prototypes only: the library is loaded on first use
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -449,11 +450,17 @@ struct rt_hip_renderer {
     uint32_t passes_done = 0;
     uint32_t tile_cursor = 0;  // tiles dispatched in the current pass (render_tile cadence)
 
-    // wavefront pipeline state (allocated on first use, see launch_wavefront)
-    std::vector<void*> wf_allocs;
-    wavefront_params wf{};
-    size_t wf_paths = 0;
-    uint32_t wf_trips = 0;
+    // wavefront pipeline state (allocated on first use, see launch_wavefront): two sets, so that
+    // two batches of one render call can be in flight side by side (set 1 only exists once a
+    // call had two batches)
+    std::vector<void*> wf_allocs[2];
+    wavefront_params wf_set[2] = {};
+    wavefront_params& wf = wf_set[0];
+    size_t wf_paths[2] = {0, 0};
+    uint32_t wf_trips[2] = {0, 0};
+    uint32_t wf_sets_in_last_call = 1;  // rt_hip_trip_counts adds up their last batches
+    hipStream_t side_stream = nullptr;  // batches on set 1 run here
+    hipEvent_t fork_event = nullptr, join_event = nullptr, resolved_event[2] = {nullptr, nullptr};
     uint32_t wf_extend_grid = 0, wf_extend_waves = 0, wf_shade_grid = 0;  // workgroups, waves
     uint32_t wf_settle_grid = 0;
     uint32_t wf_finish_grid = 0;
@@ -461,7 +468,7 @@ struct rt_hip_renderer {
     int handover_setting = -1;        // RT_HIP_HANDOVER_BELOW at creation (tuning knob), -1 = default
     wavefront_params noalloc{};       // the same arrays inside this device's scratch array
     uint32_t wf_bin_groups = 0;       // workgroups of the ray binning launches
-    bool wf_binned = false;           // the binning buffers exist
+    bool wf_binned[2] = {false, false};  // the binning buffers exist
     float scene_lo[3] = {0, 0, 0}, scene_hi[3] = {1, 1, 1};  // world bounds of the scene
     // Ray binning policy for the uploaded scene (RT_HIP_BINNING_*).  Undecided: the next
     // large enough render call runs without binning and times the trace launch of every
@@ -497,6 +504,12 @@ struct rt_hip_renderer {
     std::vector<timed_launch> event_pool;      // reusable events
     double seconds_total[3] = {0.0, 0.0, 0.0};  // per RT_HIP_KERNEL_*
     uint32_t launches_total[3] = {0, 0, 0};
+    // Two batches of a call run side by side, so launches of one kind overlap: per kind, also
+    // the time during which AT LEAST ONE such launch was running (the union of the intervals),
+    // on a time axis that starts at `time_base`.
+    double busy_seconds[3] = {0.0, 0.0, 0.0};
+    double busy_until_ms[3] = {0.0, 0.0, 0.0};  // end of the union so far
+    hipEvent_t time_base = nullptr;
 
     // One handle is driven through one stream at a time: a call on another stream than the
     // previous one first waits (on the device) for that call's work, because all calls share
@@ -542,14 +555,18 @@ struct rt_hip_renderer {
         scene_ready = false;
     }
 
-    void free_wavefront() {
-        for (void* p : wf_allocs) {
+    void free_wavefront(int set) {
+        for (void* p : wf_allocs[set]) {
             (void) hipFree(p);
         }
-        wf_allocs.clear();
-        wf_paths = 0;
-        wf_trips = 0;
-        wf_binned = false;
+        wf_allocs[set].clear();
+        wf_paths[set] = 0;
+        wf_trips[set] = 0;
+        wf_binned[set] = false;
+    }
+    void free_wavefront() {
+        free_wavefront(0);
+        free_wavefront(1);
     }
 
     timed_launch begin_timing(hipStream_t stream, uint32_t kind = RT_HIP_KERNEL_RENDER) {
@@ -562,6 +579,10 @@ struct rt_hip_renderer {
             HIP_CHECK(hipEventCreate(&t.stop));
         }
         t.kind = kind;
+        if (time_base == nullptr) {
+            HIP_CHECK(hipEventCreate(&time_base));
+            HIP_CHECK(hipEventRecord(time_base, stream));
+        }
         HIP_CHECK(hipEventRecord(t.start, stream));
         return t;
     }
@@ -573,15 +594,34 @@ struct rt_hip_renderer {
         }
     }
     void fold_timings() {
+        struct interval {
+            double from, to;
+            uint32_t kind;
+        };
+        std::vector<interval> spans;
+        spans.reserve(launches.size());
         for (timed_launch& t : launches) {
             HIP_CHECK(hipEventSynchronize(t.stop));
-            float ms = 0.0f;
+            float ms = 0.0f, from = 0.0f;
             HIP_CHECK(hipEventElapsedTime(&ms, t.start, t.stop));
+            HIP_CHECK(hipEventElapsedTime(&from, time_base, t.start));
             seconds_total[t.kind] += (double) ms * 1e-3;
             ++launches_total[t.kind];
+            spans.push_back({(double) from, (double) from + (double) ms, t.kind});
             event_pool.push_back(t);
         }
         launches.clear();
+        // union per kind: intervals in order of their start, each counted from where the union
+        // so far ends
+        std::sort(spans.begin(), spans.end(),
+            [](interval const& a, interval const& b) { return a.from < b.from; });
+        for (interval const& v : spans) {
+            double const from = std::max(v.from, busy_until_ms[v.kind]);
+            if (v.to > from) {
+                busy_seconds[v.kind] += (v.to - from) * 1e-3;
+                busy_until_ms[v.kind] = v.to;
+            }
+        }
     }
 };
 
@@ -995,39 +1035,62 @@ void init_launch_plan(rt_hip_renderer& r) {
     r.wf_stat_waves = std::max({r.wf_extend_waves, r.wf_shade_grid * (kShadeThreads / 64u),
         r.wf_settle_grid * (kSettleThreads / 64u), r.wf_finish_grid});
     size_t const stat_bytes = (size_t) r.wf_stat_waves * kStatWords * sizeof(unsigned long long);
-    HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, stat_bytes));
-    HIP_CHECK(hipMemset(r.wf.wave_stats, 0, stat_bytes));
+    // (one array, one half per state set: batches in flight side by side count separately)
+    HIP_CHECK(hipMalloc((void**) &r.wf.wave_stats, 2u * stat_bytes));
+    HIP_CHECK(hipMemset(r.wf.wave_stats, 0, 2u * stat_bytes));
+    r.wf_set[1].wave_stats = r.wf.wave_stats + (size_t) r.wf_stat_waves * kStatWords;
 }
 
-void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool binned) {
+// A render call of at least this many paths is cut into two batches even when one would hold
+// it (see "two batches in flight" in launch_wavefront): 1280x720 x 64 passes as 2 x 32 is 2 %
+// faster than as one batch although the halves' launches are smaller.
+constexpr size_t kSplitMinPaths = (size_t) 1 << 24;
+
+// Points `w` at the state arrays, lists and counters of `set`.
+void take_state_arrays(wavefront_params& w, wavefront_params const& set) {
+    w.ray_o = set.ray_o, w.ray_d = set.ray_d, w.sh_o = set.sh_o, w.sh_d = set.sh_d;
+    w.nee = set.nee, w.thr = set.thr, w.rad = set.rad, w.hit0 = set.hit0, w.hit1 = set.hit1;
+    w.occluded = set.occluded, w.live = set.live, w.q_closest = set.q_closest;
+    w.q_shadow = set.q_shadow, w.raw = set.raw, w.going = set.going;
+    w.going_count = set.going_count, w.chunk_counts = set.chunk_counts;
+    w.tile_sums = set.tile_sums, w.control = set.control;
+    w.binned_closest = set.binned_closest, w.binned_shadow = set.binned_shadow;
+    w.bin_keys_closest = set.bin_keys_closest, w.bin_keys_shadow = set.bin_keys_shadow;
+    w.bin_hist = set.bin_hist, w.bin_total = set.bin_total;
+    w.wave_stats = set.wave_stats;
+}
+
+void ensure_wavefront(rt_hip_renderer& r, int set, size_t paths, uint32_t trips, bool binned) {
     auto alloc = [&](size_t bytes) {
         void* d = nullptr;
         HIP_CHECK(hipMalloc(&d, bytes));
-        r.wf_allocs.push_back(d);
+        r.wf_allocs[set].push_back(d);
         return d;
     };
+    wavefront_params& w = r.wf_set[set];
     auto alloc_binning = [&](size_t for_paths) {
-        wavefront_params& w = r.wf;
         w.binned_closest = (uint32_t*) alloc(for_paths * 4);
         w.binned_shadow = (uint32_t*) alloc(for_paths * 4);
         w.bin_keys_closest = (uint16_t*) alloc(for_paths * 2);
         w.bin_keys_shadow = (uint16_t*) alloc(for_paths * 2);
         w.bin_hist = (uint32_t*) alloc((size_t) 2u * kBinCount * r.wf_bin_groups * 4);
         w.bin_total = (uint32_t*) alloc((size_t) 2u * kBinCount * 4);
-        r.wf_binned = true;
+        r.wf_binned[set] = true;
     };
-    if (paths <= r.wf_paths && trips <= r.wf_trips) {
-        if (binned && !r.wf_binned) {
-            alloc_binning(r.wf_paths);  // binning was switched on: add its buffers, keep the rest
+    if (paths <= r.wf_paths[set] && trips <= r.wf_trips[set]) {
+        if (binned && !r.wf_binned[set]) {
+            alloc_binning(r.wf_paths[set]);  // binning was switched on: add its buffers, keep the rest
         }
         return;
     }
-    paths = std::max(paths, r.wf_paths);
-    trips = std::max(trips, r.wf_trips);
-    binned = binned || r.wf_binned;
+    paths = std::max(paths, r.wf_paths[set]);
+    trips = std::max(trips, r.wf_trips[set]);
+    binned = binned || r.wf_binned[set];
     HIP_CHECK(hipDeviceSynchronize());
-    r.free_wavefront();
-    wavefront_params& w = r.wf;
+    unsigned long long* const wave_stats = w.wave_stats;  // outlives the regrowth
+    r.free_wavefront(set);
+    w = wavefront_params{};
+    w.wave_stats = wave_stats;
     w.ray_o = (float4*) alloc(paths * 16);
     w.ray_d = (float4*) alloc(paths * 16);
     w.sh_o = (float4*) alloc(paths * 16);
@@ -1048,8 +1111,8 @@ void ensure_wavefront(rt_hip_renderer& r, size_t paths, uint32_t trips, bool bin
     w.chunk_counts = (uint32_t*) alloc(chunks * 4);
     w.tile_sums = (uint32_t*) alloc(((chunks + kTileChunks - 1u) / kTileChunks) * 12);
     w.control = (uint32_t*) alloc((size_t) (trips + 1u) * kCtlWords * 4);
-    r.wf_paths = paths;
-    r.wf_trips = trips;
+    r.wf_paths[set] = paths;
+    r.wf_trips[set] = trips;
     if (binned) {
         alloc_binning(paths);
     }
@@ -1078,8 +1141,14 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                                  std::to_string(limit) +
                                  " one batch can hold; render it as smaller rectangles");
     }
-    uint32_t const batch =
-        (uint32_t) std::min<size_t>(p.pass_count, std::max<size_t>(1, limit / per_pass));
+    // Batches: as few as the state arrays allow - but at least two when the call is large
+    // enough, because two batches run side by side on two streams (below).
+    size_t const most = std::max<size_t>(1, limit / per_pass);  // passes one batch can hold
+    uint32_t batches = (uint32_t) ((p.pass_count + most - 1u) / most);
+    if (!fixed && p.pass_count >= 2u && per_pass * p.pass_count >= kSplitMinPaths) {
+        batches = std::max(batches, 2u);
+    }
+    uint32_t const batch = (p.pass_count + batches - 1u) / batches;
     uint32_t const trips = p.max_depth + 1u;
     if (!fixed) {
         settle_probe(r);
@@ -1140,9 +1209,33 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
             r.probe_counts_trips = trips;
         }
     }
+    // Two batches in flight side by side.  Late bounces leave most of the GPU idle: few paths
+    // are alive, every launch still waits for its slowest wave, and the launches of one batch
+    // depend on each other.  A second batch with its own path state on a second stream fills
+    // those gaps with its early, full launches (measured: two independent 64-pass renders of
+    // the 1280x720 frame issued together finish 12 % sooner than one after the other; three or
+    // four in flight are slower again).  Batch b runs on set b % 2; set 0 on the caller's
+    // stream, set 1 on a stream of the renderer's own that starts after everything the caller
+    // has queued so far and that the caller's stream waits for at the end.  A pixel's passes are
+    // still added in pass order: each batch's resolve launch waits for the previous batch's.
+    // A measured call (probe) keeps to one stream, so that its launch times mean something.
+    uint32_t const lanes = (!fixed && !probe && p.pass_count > batch) ? 2u : 1u;
     if (!fixed) {
-        ensure_wavefront(r, per_pass * batch, trips, binned);
+        ensure_wavefront(r, 0, per_pass * batch, trips, binned);
+        if (lanes == 2u) {
+            ensure_wavefront(r, 1, per_pass * batch, trips, binned);
+            if (r.side_stream == nullptr) {
+                HIP_CHECK(hipStreamCreateWithFlags(&r.side_stream, hipStreamNonBlocking));
+                HIP_CHECK(hipEventCreateWithFlags(&r.fork_event, hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&r.join_event, hipEventDisableTiming));
+                for (hipEvent_t& e : r.resolved_event) {
+                    HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+                }
+            }
+        }
+        r.wf_sets_in_last_call = lanes;
     }
+    hipStream_t lane_stream = stream;  // the stream of the batch being issued
 
     wavefront_params w = fixed ? *fixed : r.wf;
     w.sort_rays = 0u;  // set per trip below
@@ -1206,7 +1299,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         dim3 const block(reference ? 64u : kExtendThreads);
         uint32_t const lds = reference ? 0u : extend_lds;
         auto go = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, grid, block, lds, stream, w, trip);
+            hipLaunchKernelGGL(kernel, grid, block, lds, lane_stream, w, trip);
         };
         bool const first = trip == 0u;
         if (reference) {
@@ -1237,18 +1330,18 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
         if (r.cfg.accel == RT_HIP_ACCEL_REFERENCE) {
             if (count) {
                 hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REFERENCE, true>), grid, dim3(64),
-                    0, stream, w, trip);
+                    0, lane_stream, w, trip);
             } else {
                 hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REFERENCE, false>), grid,
-                    dim3(64), 0, stream, w, trip);
+                    dim3(64), 0, lane_stream, w, trip);
             }
         } else {
             if (count) {
                 hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REBUILT, true>), grid, dim3(64),
-                    0, stream, w, trip);
+                    0, lane_stream, w, trip);
             } else {
                 hipLaunchKernelGGL((wf_finish_kernel<RT_HIP_ACCEL_REBUILT, false>), grid, dim3(64),
-                    0, stream, w, trip);
+                    0, lane_stream, w, trip);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -1257,25 +1350,25 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     auto compact = [&](uint32_t trip, const uint32_t* in_count_ptr, uint32_t in_count,
                        uint32_t chunk_bound, uint32_t handover_below) {
         dim3 const tiles(std::max(1u, (chunk_bound + kTileChunks - 1u) / kTileChunks));
-        hipLaunchKernelGGL(wf_tile_sums_kernel, tiles, dim3(kTileThreads), 0, stream, w,
+        hipLaunchKernelGGL(wf_tile_sums_kernel, tiles, dim3(kTileThreads), 0, lane_stream, w,
             in_count_ptr, in_count);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(wf_scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, stream, w, trip,
+        hipLaunchKernelGGL(wf_scan_tiles_kernel, dim3(1), dim3(kScanThreads), 0, lane_stream, w, trip,
             in_count_ptr, in_count, handover_below);
         HIP_CHECK(hipGetLastError());
-        hipLaunchKernelGGL(wf_scatter_kernel, tiles, dim3(kTileThreads), 0, stream, w,
+        hipLaunchKernelGGL(wf_scatter_kernel, tiles, dim3(kTileThreads), 0, lane_stream, w,
             in_count_ptr, in_count);
         HIP_CHECK(hipGetLastError());
         if (trip_binned(trip)) {
             dim3 const shares(r.wf_bin_groups, 2u);
-            hipLaunchKernelGGL(wf_bin_count_kernel, shares, dim3(kBinThreads), kBinCount * 4u, stream, w, trip);
+            hipLaunchKernelGGL(wf_bin_count_kernel, shares, dim3(kBinThreads), kBinCount * 4u, lane_stream, w, trip);
             HIP_CHECK(hipGetLastError());
             hipLaunchKernelGGL(wf_bin_columns_kernel, dim3(kBinCount / kBinColumnThreads, 2u),
-                dim3(kBinColumnThreads), 0, stream, w, trip, r.wf_bin_groups);
+                dim3(kBinColumnThreads), 0, lane_stream, w, trip, r.wf_bin_groups);
             HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL(wf_bin_bases_kernel, dim3(2u), dim3(kBinThreads), 0, stream, w, trip);
+            hipLaunchKernelGGL(wf_bin_bases_kernel, dim3(2u), dim3(kBinThreads), 0, lane_stream, w, trip);
             HIP_CHECK(hipGetLastError());
-            hipLaunchKernelGGL(wf_bin_place_kernel, shares, dim3(kBinThreads), kBinCount * 4u, stream, w, trip);
+            hipLaunchKernelGGL(wf_bin_place_kernel, shares, dim3(kBinThreads), kBinCount * 4u, lane_stream, w, trip);
             HIP_CHECK(hipGetLastError());
         }
     };
@@ -1284,12 +1377,24 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     if (!fixed) {
         whole = r.begin_timing(stream);
     }
-    for (uint32_t first = 0; first < p.pass_count; first += batch) {
+    if (lanes == 2u) {
+        HIP_CHECK(hipEventRecord(r.fork_event, stream));
+        HIP_CHECK(hipStreamWaitEvent(r.side_stream, r.fork_event, 0));
+    }
+    wavefront_params const frame = w;  // everything but the state arrays of a set
+    uint32_t issued = 0;
+    for (uint32_t first = 0; first < p.pass_count; first += batch, ++issued) {
+        uint32_t const set = issued % lanes;
+        lane_stream = set == 0u ? stream : r.side_stream;
+        if (!fixed) {
+            w = frame;
+            take_state_arrays(w, r.wf_set[set]);
+        }
         w.pass_count = std::min(batch, p.pass_count - first);
         w.seeds = p.seeds ? p.seeds + (size_t) first * p.tile_count : nullptr;
         size_t const paths = per_pass * w.pass_count;
         uint32_t const chunk_bound = (uint32_t) (paths / 64u);
-        HIP_CHECK(hipMemsetAsync(w.control, 0, (size_t) (trips + 1u) * kCtlWords * 4, stream));
+        HIP_CHECK(hipMemsetAsync(w.control, 0, (size_t) (trips + 1u) * kCtlWords * 4, lane_stream));
         uint32_t const handover_below =
             handover_setting >= 0 ? (uint32_t) handover_setting
                                   : (uint32_t) std::max<size_t>(paths / 256u, 65536u);
@@ -1306,21 +1411,21 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                 (region_bound + kShadeThreads / 64u - 1u) / (kShadeThreads / 64u)));
             rt_hip_renderer::timed_launch t{};
             if (each) {
-                t = r.begin_timing(stream, RT_HIP_KERNEL_EXTEND);
+                t = r.begin_timing(lane_stream, RT_HIP_KERNEL_EXTEND);
             }
             bool const probe_here = probe;
             if (probe_here) {
-                HIP_CHECK(hipEventRecord(r.probe_events[2 * trip], stream));
+                HIP_CHECK(hipEventRecord(r.probe_events[2 * trip], lane_stream));
             }
             w.sort_rays = trip_binned(trip) ? 1u : 0u;
             w.refill = trip_refills(trip) ? 1u : 0u;
             extend(trip, trip == 0u ? chunk_bound : 2u * chunk_bound);
             if (probe_here) {
-                HIP_CHECK(hipEventRecord(r.probe_events[2 * trip + 1], stream));
+                HIP_CHECK(hipEventRecord(r.probe_events[2 * trip + 1], lane_stream));
                 if (trip + 1u == trips) {
                     HIP_CHECK(hipMemcpyAsync(r.probe_counts, w.control,
-                        (size_t) trips * kCtlWords * 4, hipMemcpyDeviceToHost, stream));
-                    HIP_CHECK(hipEventRecord(r.probe_done, stream));
+                        (size_t) trips * kCtlWords * 4, hipMemcpyDeviceToHost, lane_stream));
+                    HIP_CHECK(hipEventRecord(r.probe_done, lane_stream));
                     r.probe_pending = true;
                     r.probe_trips = trips;
                     r.probe_kind = probe_kind;
@@ -1328,17 +1433,17 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                 }
             }
             if (each) {
-                r.end_timing(t, stream);
-                t = r.begin_timing(stream, RT_HIP_KERNEL_SHADE);
+                r.end_timing(t, lane_stream);
+                t = r.begin_timing(lane_stream, RT_HIP_KERNEL_SHADE);
             }
 #ifdef RT_EXP_F
             launch_shade_stage<(uint32_t) (RT_EXP_F)>(w, trip, settle_grid, shade_grid, shade_lds,
-                stream);
+                lane_stream);
 #else
             switch (r.shade_variant) {
 #define RT_LAUNCH_SHADE(F)                                                                 \
     case F:                                                                                \
-        launch_shade_stage<F>(w, trip, settle_grid, shade_grid, shade_lds, stream);        \
+        launch_shade_stage<F>(w, trip, settle_grid, shade_grid, shade_lds, lane_stream);        \
         break;
                 RT_SHADE_VARIANTS(RT_LAUNCH_SHADE)
 #undef RT_LAUNCH_SHADE
@@ -1348,7 +1453,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
 #endif
             HIP_CHECK(hipGetLastError());
             if (each) {
-                r.end_timing(t, stream);
+                r.end_timing(t, lane_stream);
             }
             if (trip + 1u < trips) {
                 // nothing survives the last trip: its paths are at max_depth
@@ -1357,9 +1462,20 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
                     (uint32_t) paths, chunk_bound, handover_below);
             }
         }
+        if (lanes == 2u && issued > 0u) {
+            // the pixel's earlier passes first (the previous batch ran on the other set)
+            HIP_CHECK(hipStreamWaitEvent(lane_stream, r.resolved_event[(issued - 1u) % 2u], 0));
+        }
         hipLaunchKernelGGL(wf_resolve_kernel, dim3((uint32_t) ((per_pass + 255u) / 256u)),
-            dim3(256), 0, stream, w);
+            dim3(256), 0, lane_stream, w);
         HIP_CHECK(hipGetLastError());
+        if (lanes == 2u) {
+            HIP_CHECK(hipEventRecord(r.resolved_event[issued % 2u], lane_stream));
+        }
+    }
+    if (lanes == 2u) {
+        HIP_CHECK(hipEventRecord(r.join_event, r.side_stream));
+        HIP_CHECK(hipStreamWaitEvent(stream, r.join_event, 0));
     }
     if (!fixed) {
         r.end_timing(whole, stream);
@@ -2022,10 +2138,19 @@ int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t
         if (per_pass > kWavefrontMaxPaths) {
             throw std::runtime_error("reserve: one pass of that rectangle exceeds one batch");
         }
-        size_t const batch = std::min<size_t>(pass_count, std::max<size_t>(1, kWavefrontMaxPaths / per_pass));
+        // (the batches launch_wavefront would cut such a call into)
+        size_t const most = std::max<size_t>(1, kWavefrontMaxPaths / per_pass);
+        uint32_t batches = (uint32_t) ((pass_count + most - 1u) / most);
+        if (pass_count >= 2u && per_pass * pass_count >= kSplitMinPaths) {
+            batches = std::max(batches, 2u);
+        }
+        size_t const batch = (pass_count + batches - 1u) / batches;
         device_scope const on_device(r->device);
         bool const binned = r->binning != RT_HIP_BINNING_OFF;  // decided later: be ready for it
-        ensure_wavefront(*r, per_pass * batch, r->cfg.max_depth + 1u, binned);
+        ensure_wavefront(*r, 0, per_pass * batch, r->cfg.max_depth + 1u, binned);
+        if (batches >= 2u) {
+            ensure_wavefront(*r, 1, per_pass * batch, r->cfg.max_depth + 1u, binned);
+        }
     });
 }
 
@@ -2344,7 +2469,7 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
         HIP_CHECK(hipMemcpy(words, r->counters, sizeof(words), hipMemcpyDeviceToHost));
         if (r->wf.wave_stats != nullptr) {
             // the pipeline keeps its work counters per wave
-            size_t const waves = r->wf_stat_waves;
+            size_t const waves = 2u * (size_t) r->wf_stat_waves;  // both state sets' halves
             std::vector<unsigned long long> per_wave(waves * kStatWords);
             HIP_CHECK(hipMemcpy(per_wave.data(), r->wf.wave_stats,
                 per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -2386,6 +2511,7 @@ int rt_hip_stats(rt_hip_renderer* r, rt_stats* out, int reset) {
             for (int k = 0; k < 3; ++k) {
                 r->seconds_total[k] = 0.0;
                 r->launches_total[k] = 0;
+                r->busy_seconds[k] = 0.0;
             }
         }
     });
@@ -2413,22 +2539,40 @@ int rt_hip_kernel_time_of(rt_hip_renderer* r, uint32_t kernel, double* avg_ms,
     });
 }
 
+int rt_hip_kernel_busy_of(rt_hip_renderer* r, uint32_t kernel, double* busy_ms) {
+    return guarded([&] {
+        if (!r || !busy_ms) {
+            throw std::runtime_error("kernel_busy_of: null argument");
+        }
+        if (kernel > RT_HIP_KERNEL_SHADE) {
+            throw std::runtime_error("kernel_busy_of: unknown kernel");
+        }
+        device_scope const on_device(r->device);
+        r->fold_timings();
+        *busy_ms = r->busy_seconds[kernel] * 1e3;
+    });
+}
+
 int rt_hip_trip_counts(rt_hip_renderer* r, uint32_t trip, uint32_t* counts) {
     return guarded([&] {
         if (!r || !counts) {
             throw std::runtime_error("trip_counts: null argument");
         }
-        if (r->wf_allocs.empty() || trip >= r->wf_trips) {
+        if (r->wf_allocs[0].empty() || trip >= r->wf_trips[0]) {
             throw std::runtime_error("trip_counts: no pipeline batch has run that many trips");
         }
         device_scope const on_device(r->device);
         HIP_CHECK(hipDeviceSynchronize());
-        uint32_t words[kCtlWords];
-        HIP_CHECK(hipMemcpy(words, r->wf.control + (size_t) trip * kCtlWords, sizeof(words),
-            hipMemcpyDeviceToHost));
-        counts[0] = words[kCtlLive];
-        counts[1] = words[kCtlClosest];
-        counts[2] = words[kCtlShadow];
+        counts[0] = counts[1] = counts[2] = 0;
+        // a call of two batches ran one on each state set: their last batches together
+        for (uint32_t set = 0; set < r->wf_sets_in_last_call; ++set) {
+            uint32_t words[kCtlWords];
+            HIP_CHECK(hipMemcpy(words, r->wf_set[set].control + (size_t) trip * kCtlWords,
+                sizeof(words), hipMemcpyDeviceToHost));
+            counts[0] += words[kCtlLive];
+            counts[1] += words[kCtlClosest];
+            counts[2] += words[kCtlShadow];
+        }
     });
 }
 
@@ -2443,10 +2587,11 @@ int rt_hip_trace_work(rt_hip_renderer* r, rt_hip_trace_work_counts* out) {
         if (r->wf.wave_stats == nullptr) {
             return;
         }
-        std::vector<unsigned long long> per_wave((size_t) r->wf_stat_waves * kStatWords);
+        size_t const waves = 2u * (size_t) r->wf_stat_waves;  // both state sets' halves
+        std::vector<unsigned long long> per_wave(waves * kStatWords);
         HIP_CHECK(hipMemcpy(per_wave.data(), r->wf.wave_stats,
             per_wave.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        for (size_t wv = 0; wv < r->wf_stat_waves; ++wv) {
+        for (size_t wv = 0; wv < waves; ++wv) {
             unsigned long long const* s = &per_wave[wv * kStatWords];
             out->nodes += s[kStatNodes];
             out->tris += s[kStatTris];
@@ -2556,6 +2701,16 @@ int rt_hip_destroy(rt_hip_renderer* r) {
             (void) hipEventDestroy(e);
         }
         (void) hipEventDestroy(r->probe_done);
+        if (r->time_base != nullptr) {
+            (void) hipEventDestroy(r->time_base);
+        }
+        if (r->side_stream != nullptr) {
+            (void) hipStreamDestroy(r->side_stream);
+            (void) hipEventDestroy(r->fork_event);
+            (void) hipEventDestroy(r->join_event);
+            (void) hipEventDestroy(r->resolved_event[0]);
+            (void) hipEventDestroy(r->resolved_event[1]);
+        }
         (void) hipEventDestroy(r->last_done);
         if (r->probe_counts) {
             (void) hipHostFree(r->probe_counts);

@@ -339,9 +339,10 @@ __global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_p
         ctl[kCtlFinish] = handover ? incl.live : 0u;
         if (!handover) {
             // the finishing kernel counts the rays it traces itself; single thread of a
-            // single workgroup, and launches of one renderer are stream-ordered
-            p.counters[1] += incl.closest;
-            p.counters[2] += incl.shadow;
+            // single workgroup - but two batches of a render call run side by side on two
+            // streams, so the two scans may add at the same time
+            atomicAdd(&p.counters[1], (unsigned long long) incl.closest);
+            atomicAdd(&p.counters[2], (unsigned long long) incl.shadow);
         }
     }
 }

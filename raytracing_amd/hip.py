@@ -36,7 +36,7 @@ EXPORTS = [
     "rt_hip_render", "rt_hip_reserve", "rt_hip_tune", "rt_hip_shade_features", "rt_hip_render_noalloc", "rt_hip_render_tile", "rt_hip_render_preview", "rt_hip_primary_ids",
     "rt_hip_probe", "rt_hip_triangle_never_hit", "rt_hip_read_accum", "rt_hip_read_preview", "rt_hip_accum_ptr", "rt_hip_passes",
     "rt_hip_set_passes", "rt_hip_reduce",
-    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_trip_counts",
+    "rt_hip_stats", "rt_hip_kernel_time", "rt_hip_kernel_time_of", "rt_hip_kernel_busy_of", "rt_hip_trip_counts",
     "rt_hip_trace_work", "rt_hip_trace_refill", "rt_hip_ray_binning", "rt_hip_destroy", "rt_hip_last_error",
 ]
 
@@ -141,6 +141,7 @@ def lib():
         l.rt_hip_stats.argtypes = [C.c_void_p, C.POINTER(T.Stats), C.c_int]
         l.rt_hip_kernel_time.argtypes = [C.c_void_p, C.POINTER(C.c_double), u32p]
         l.rt_hip_kernel_time_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double), u32p]
+        l.rt_hip_kernel_busy_of.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_double)]
         l.rt_hip_trip_counts.argtypes = [C.c_void_p, C.c_uint32, u32p]
         l.rt_hip_trace_work.argtypes = [C.c_void_p, C.POINTER(TraceWork)]
         l.rt_hip_ray_binning.argtypes = [C.c_void_p, u32p, C.POINTER(C.c_double)]
@@ -274,6 +275,12 @@ class HipRenderer:
         n = C.c_uint32()
         _check(lib().rt_hip_kernel_time_of(self._h, kernel, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def kernel_busy(self, kernel):
+        """Milliseconds during which at least one launch of that kind was running."""
+        ms = C.c_double()
+        _check(lib().rt_hip_kernel_busy_of(self._h, kernel, C.byref(ms)))
+        return ms.value
 
     def ray_binning(self):
         """(BINNING_* state for the uploaded scene, measured ns per third-bounce ray or 0.0)."""

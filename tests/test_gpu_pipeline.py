@@ -425,6 +425,36 @@ def test_refill_measurement_compares_calls_of_different_size_per_ray(hyperion):
         r.close()
 
 
+def test_two_batches_in_flight_side_by_side(hyperion):
+    """A call of at least 2^24 paths runs as two (or more) batches, two at a time on two
+    streams with a set of path state each; a pixel's passes are still added in pass order, so
+    image and work counters equal the fused kernel's, which runs them in one launch - also
+    when a second call follows at once on the same stream and reuses both sets, and with three
+    batches (the third waits for the first one's set)."""
+    w, h, md, tile, spp = 640, 800, 7, (64, 80), 36      # 18.4 M paths: two batches of 18 passes
+    fused = run(hyperion, w, h, md, tile, 2 * spp, hip.ACCEL_REBUILT,
+                hip.FLAG_FUSED | hip.FLAG_COUNT_NODES)
+    r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT,
+                        flags=hip.FLAG_COUNT_NODES | hip.FLAG_TRACE_REFILL | hip.FLAG_NO_BIN_RAYS)
+    try:
+        r.upload_scene(hyperion.desc)
+        r.upload_seeds(host.seed_schedule(0, 2 * spp, r.tile_count))
+        cam = hyperion.camera(w, h)
+        r.clear()
+        r.render(cam, 0, spp)          # two batches side by side
+        r.render(cam, spp, spp)        # and again, without waiting
+        img, passes = r.read_accum()
+        st = r.stats()
+        live = [r.trip_counts(t)[0] for t in range(md + 1)]
+    finally:
+        r.close()
+    assert passes == 2 * spp and same(img, fused[0])
+    for k in COUNTERS:
+        assert st[k] == fused[2][k], k
+    # the last call's two batches together: every path of its 36 passes was alive at bounce 0
+    assert live[0] == w * h * spp and all(a >= b for a, b in zip(live, live[1:]))
+
+
 def test_calls_on_different_streams_of_one_handle_are_ordered(hyperion):
     """A handle's calls share its path state and counters.  Issued on two different streams
     back to back (no host synchronisation in between), the second must wait for the first on
