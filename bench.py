@@ -496,6 +496,9 @@ def roofline_of(w, m):
     roofline = {
         "bound": bound,
         "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+        "frac_of_each_level": {"l2": achieved / L2_PEAK_GBS,
+                               "infinity-cache": achieved / INFINITY_CACHE_GATHER_GBS,
+                               "hbm": achieved / HBM_PEAK_GBS},
         "traffic": traffic,
         "kernel": name, "kernel_avg_ms": ms, "kernel_avg_ms_wall": ms_wall, "launches": n,
         "kernel_avg_ms_definition": "two batches of a render call are in flight side by side, "
@@ -514,7 +517,11 @@ def roofline_of(w, m):
                       "of the hottest nodes serves the rest: lds_served_*).  bound/peak: where "
                       "nodes + triangles + instance records stay resident - one XCD's 4 MiB L2 "
                       "slice (every XCD walks the whole structure; 34.5 TB/s over the eight), "
-                      "else the 256 MiB Infinity Cache (8.6 TB/s gather), else HBM (8 TB/s)",
+                      "else the 256 MiB Infinity Cache (8.6 TB/s gather), else HBM (8 TB/s).  A "
+                      "structure a few times the size of an L2 slice is still served mostly by "
+                      "the L2s and the CUs' own caches (the top of the tree is hot), so `frac` "
+                      "against the Infinity Cache figure can reach or pass 1 (the staircase): "
+                      "frac_of_each_level gives the same rate against all three peaks",
         "binding": "valu-issue",
         "issue_frac": issue_frac,
         "issue_frac_definition": "VALU busy share of the kernel's time x share of the 64 lanes "
