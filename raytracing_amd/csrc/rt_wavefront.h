@@ -28,8 +28,8 @@
 // see "Ray binning" below; the order inside a bin then depends on the timing of LDS atomics,
 // which no result depends on.)
 //
-// The per-trip kernels run on a fixed grid of resident waves; wave w takes chunks w, w + W,
-// w + 2W ... (list lengths exist only on the device).  Work counters are kept per wave
+// The per-trip kernels run on a fixed grid of resident waves; a wave takes chunks w, w + W, ...
+// of a list, or groups of chunks from a counter (list lengths exist only on the device).  Work counters are kept per wave
 // (wave_stats) and summed when they are read.
 #pragma once
 
@@ -45,6 +45,8 @@ enum : uint32_t {
     kCtlFinish = 3,   // entries of the live list handed to the finishing kernel instead
     kCtlRegionCursor = 4,  // next batch of regions of the `going` list to be shaded (wf_shade_kernel)
     kCtlGoing = 5,         // paths on the `going` list
+    kCtlClosestCursor = 6, // next group of chunks of the closest-hit queue (dynamic hand-out)
+    kCtlShadowCursor = 7,  // likewise for the occlusion queue
     kCtlWords = 8,
 };
 
@@ -597,8 +599,28 @@ constexpr uint32_t kExtendThreads = 1024;
 #ifndef RT_REFILL_IDLE
 #define RT_REFILL_IDLE 32
 #endif
+// The refilling trace launches hand their queue out in groups of this many 64-ray chunks, from
+// a counter in the trip's control block: one atomic per 512 rays.  A fixed share per wave (chunks
+// w, w + W, ...) left the waves with cheap rays idle at the end of every launch (hand-out by
+// counter: hyperion +1.6 %, mustang +2.5 %, staircase +3.3 %, the 10 000-instance scene +4.3 %);
+// groups of 2 chunks serialise on the counter (hyperion -15 %), 4 and 16 are within 1 % of 8,
+// 32 bring the idle tails back (-3 ... -5 %).
+#ifndef RT_HAND_OUT_CHUNKS
+#define RT_HAND_OUT_CHUNKS 8
+#endif
+constexpr uint32_t kHandOutChunks = RT_HAND_OUT_CHUNKS;
 constexpr uint32_t kRefillIdle = RT_REFILL_IDLE;  // lanes that must wait before a wave refills
 constexpr uint32_t kLdsBytesPerCu = 160u * 1024u;
+
+// First chunk of the wave's next group (all lanes get it); past the queue's end when it is
+// used up.  Which wave traces which ray has no influence on any result.
+RT_DEV uint32_t next_chunks(uint32_t* cursor) {
+    uint32_t first = 0;
+    if (wave_lane() == 0) {
+        first = atomicAdd(cursor, kHandOutChunks);
+    }
+    return (uint32_t) __builtin_amdgcn_readfirstlane((int) first);
+}
 
 // FIRST: trip 0 - the rays are the primary rays of pids 0 .. paths-1, built on the spot.
 template <int ACCEL, bool COUNT, bool FIRST>
@@ -649,26 +671,30 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
         // (the mean over the maximum of 64 is what bounds the lanes in use), so a lane whose
         // ray is done takes the wave's next ray - but only once at least kRefillIdle lanes
         // wait, so that the per-ray set-up (three exact divisions) runs on many lanes at once.
-        // Slot j of wave w is ray (w + (j / 64) W) 64 + j % 64 of the queue: the waves take the
-        // queue's 64-ray chunks round robin, as the fixed-chunk loop below does.
-        uint32_t const w = wave_index(), W = wave_total();
+        // The rays come in groups of kHandOutChunks chunks from the queue's counter (next_chunks).
         unsigned long long const below = (1ull << wave_lane()) - 1ull;
-        auto run = [&](auto walk, uint32_t n, auto fetch, auto deliver) {
+        auto run = [&](auto walk, uint32_t n, uint32_t* cursor, auto fetch, auto deliver) {
             uint32_t const chunks = (n + 63u) / 64u;
-            uint32_t const my_chunks = w < chunks ? (chunks - w + W - 1u) / W : 0u;
-            uint32_t const mine = my_chunks * 64u;  // slots; those past n have no ray
-            uint32_t next = 0;
+            uint32_t group_first = 0, group_next = kHandOutChunks * 64u;  // slots used of the group
+            bool exhausted = chunks == 0u;
             bool busy = false;
             uint32_t pid = 0;
             for (;;) {
                 unsigned long long const idle = __ballot(!busy);
                 uint32_t const idle_count = (uint32_t) __builtin_popcountll(idle);
-                if (next < mine && (idle_count >= kRefillIdle || idle_count == 64u)) {
-                    uint32_t const take = min(idle_count, mine - next);
+                if (!exhausted && (idle_count >= kRefillIdle || idle_count == 64u)) {
+                    if (group_next >= kHandOutChunks * 64u) {
+                        group_first = next_chunks(cursor);
+                        group_next = 0;
+                        if (group_first >= chunks) {
+                            exhausted = true;
+                            continue;
+                        }
+                    }
+                    uint32_t const take = min(idle_count, kHandOutChunks * 64u - group_next);
                     uint32_t const rank = (uint32_t) __builtin_popcountll(idle & below);
                     if (!busy && rank < take) {
-                        uint32_t const j = next + rank;
-                        uint32_t const i = (w + (j / 64u) * W) * 64u + j % 64u;
+                        uint32_t const i = group_first * 64u + group_next + rank;
                         f3 o, d;
                         float t_limit;
                         if (i < n && fetch(i, pid, o, d, t_limit)) {
@@ -676,7 +702,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                             busy = true;
                         }
                     }
-                    next += take;
+                    group_next += take;
                     continue;  // (lanes whose slot held no ray try again)
                 }
                 if (idle_count == 64u) {
@@ -689,6 +715,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
             }
         };
         run(fast_walk<false, COUNT, true>{}, n_closest,
+            p.control + trip * kCtlWords + kCtlClosestCursor,
             [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
                 t_limit = kInfinity;
                 if (FIRST) {
@@ -710,6 +737,7 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 stream_store(&p.hit1[pid], make_float2(wk.best.b2, wk.best.t));
             });
         run(fast_walk<true, COUNT, true>{}, n_shadow,
+            p.control + trip * kCtlWords + kCtlShadowCursor,
             [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
                 pid = stream_load(&q_shadow[i]);
                 float4 const ro = stream_load(&p.sh_o[pid]);
@@ -724,6 +752,9 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
             });
     } else
 #endif
+    // (fixed chunks, fixed shares: wave w takes chunks w, w + W, ...  This is the loop of the
+    // coherent bounces - camera rays - whose chunks cost about the same; handing them out by
+    // counter as well measured 1.6 % slower on hyperion and 2.7 % on the teapot scene)
     for (uint32_t chunk = wave_index(); chunk < total_chunks; chunk += wave_total()) {
         if (chunk < closest_chunks) {
             uint32_t const i = chunk * 64u + wave_lane();
