@@ -410,7 +410,8 @@ def count_work(env, w, sc, cam, accel, seeds_row, refill):
         r.render(cam, 0, w.spp_per_step)
         st = r.stats()
         work = r.trace_work()
-        per_bounce = [r.trip_counts(t) for t in range(w.max_depth + 1)]
+        per_bounce = ([] if w.pipeline == "fused"   # (the fused kernel keeps no lists)
+                      else [r.trip_counts(t) for t in range(w.max_depth + 1)])
     finally:
         r.close()
     return st, work, per_bounce
@@ -438,7 +439,7 @@ def roofline_of(w, m):
         name, ms, n = "path_trace_kernel", m["render_ms"], m["render_calls"]
         ms_wall = ms
         closest_l, shadow_l = cst["closest_rays"], cst["shadow_rays"]
-        nodes_l, tris_l = work["nodes"], work["tris"]
+        nodes_l, tris_l = cst["nodes_visited"], cst["tris_tested"]  # (its own counters)
         launches_per_call = 1
     else:
         name, ms_wall, n = "wf_extend_kernel", m["extend_ms"], m["extend_n"]
