@@ -4,8 +4,9 @@
     python bench.py --gpus N --steps K --warmup W [--scene NAME] [--total-spp S]
 
 One step = one rt_hip_render call over the whole frame at max_depth 7, tracing --spp-per-step
-passes of every pixel (scene, seeds and accumulator already resident in HBM; default 128 passes,
-which the library traces as two batches of 64 side by side on two streams).  The reported
+passes of every pixel (scene, seeds and accumulator already resident in HBM; default 512 passes,
+which the library traces as two batches of 256 side by side on two streams: 2 x 236 M paths,
+78 GB of path state of the 288 GB).  The reported
 value is pixel-samples per second over all GPUs, in Msamples/s; Mrays/s comes from the device
 ray counters of the same timed region.
 
@@ -67,9 +68,9 @@ REF_NODE_BYTES = 32
 REF_TRI_BYTES = 36
 
 DEFAULT_SCENE = "hyperion_rect_light"
-DEFAULT_SPP = 128       # per render call: two batches of 64 passes = 59 M paths each
+DEFAULT_SPP = 512       # per render call: two batches of 256 passes = 236 M paths each
 DEFAULTS = {  # scene -> (width, height, spp per step)
-    "synthetic_4k": (3840, 2160, 16),  # two batches of 8 passes = 66.4 M paths each
+    "synthetic_4k": (3840, 2160, 64),  # two batches of 32 passes = 265 M paths each
 }
 # the other configurations of the baseline: (scene, seconds of CPU baseline)
 OTHER_SCENES = (("mustang_red_reduced", 6.0), ("cornell_box", 3.0), ("staircase_reduced", 3.0),

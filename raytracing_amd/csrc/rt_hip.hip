@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -864,10 +865,18 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
     }
 }
 
-// Paths in flight per batch of the wavefront pipeline: 2^26 paths = 9.4 GB of state (of 288 GB).
-// Large batches amortise the launch tails: 64 passes of a 1280x720 frame per batch render 1.15x
-// faster per sample than 16.
-constexpr size_t kWavefrontMaxPaths = (size_t) 1 << 26;
+// Paths in flight per batch of the wavefront pipeline: at most 2^28 (164 B of state, lists and
+// counters per path, 176 B with the ray binning's buffers: 44-47 GB per state set, two sets for
+// two batches in flight, of 288 GB).  Large batches amortise launch tails and give the late,
+// sparse bounces launches worth starting: per sample, 1280x720 renders 1.15x faster at 64 passes
+// per batch than at 16, and 1.04x / 1.10x faster again at 128 / 256 (two batches in flight each
+// time).  The state arrays are allocated for the batches a caller actually asks for, and a
+// batch never takes more than its share of HALF the device memory that is free (batch_limit).
+#ifndef RT_MAX_PATHS_LOG2
+#define RT_MAX_PATHS_LOG2 28
+#endif
+constexpr size_t kWavefrontMaxPaths = (size_t) 1 << RT_MAX_PATHS_LOG2;
+constexpr size_t kStateBytesPerPath = 176;
 
 // Regrouping a trip's ray queues is worth its launches when tracing one of its rays costs more
 // than kBinningPaysAboveNs nanoseconds of whole-GPU time and the trip has enough rays to pay for
@@ -1118,6 +1127,41 @@ void ensure_wavefront(rt_hip_renderer& r, int set, size_t paths, uint32_t trips,
     }
 }
 
+// The hard bound on a batch: kWavefrontMaxPaths, or less when the environment variable
+// RT_HIP_MAX_BATCH_PATHS asks for it (a process that shares the device and wants this renderer's
+// state arrays small; read on every call, so it can be changed between calls).
+size_t batch_cap() {
+    size_t cap = kWavefrontMaxPaths;
+    if (const char* text = std::getenv("RT_HIP_MAX_BATCH_PATHS")) {
+        char* end = nullptr;
+        unsigned long long const asked = std::strtoull(text, &end, 0);
+        if (end != text && *end == '\0' && asked >= 64u) {
+            cap = std::min<size_t>(cap, (size_t) asked);
+        }
+    }
+    return cap;
+}
+
+// Most paths one batch may hold right now: batch_cap(), or less when the device is short of
+// memory - both state sets together (two batches in flight) stay within half of what is free,
+// counting what the renderer holds already as free.  One pass of the rectangle is the smallest
+// batch there is, so up to the cap `per_pass` is always allowed (its allocation then succeeds or
+// fails as such); a pass beyond the cap gets the cap, and the caller refuses it.
+size_t batch_limit(rt_hip_renderer const& r, size_t per_pass) {
+    size_t const cap = batch_cap();
+    size_t free_bytes = 0, total_bytes = 0;
+    if (per_pass >= cap) {
+        return cap;
+    }
+    if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) {
+        (void) hipGetLastError();
+        return cap;
+    }
+    size_t const held = (r.wf_paths[0] + r.wf_paths[1]) * kStateBytesPerPath;
+    size_t const affordable = (free_bytes + held) / 2u / (2u * kStateBytesPerPath);
+    return std::min(cap, std::max(per_pass, affordable));
+}
+
 // rt_hip_render through the wavefront pipeline (rt_wavefront.h).
 //
 // `fixed` = nullptr: the pipeline state lives in the renderer's own device allocations, grown on
@@ -1129,10 +1173,10 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     uint32_t const blocks_x = (p.x1 - p.x0 + 7u) / 8u;
     uint32_t const blocks_y = (p.y1 - p.y0 + 7u) / 8u;
     size_t const per_pass = (size_t) blocks_x * blocks_y * 64u;
-    static_assert(kWavefrontMaxPaths / 64u / kTileChunks <= kScanThreads,
+    static_assert(kWavefrontMaxPaths / 64u / kTileChunks <= kScanThreads * kScanTilesPerThread,
         "one workgroup must be able to scan the tile sums");
     static_assert(kWavefrontMaxPaths <= (size_t) kLivePidMask + 1u, "a pid must fit a list entry");
-    size_t const limit = fixed ? fixed_paths : kWavefrontMaxPaths;
+    size_t const limit = fixed ? fixed_paths : batch_limit(r, per_pass);
     if (per_pass > limit) {
         // one pass of the rectangle is the smallest batch; the compaction (one workgroup scans
         // the tile sums) and the state arrays are sized for `limit` paths
@@ -2135,17 +2179,17 @@ int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t
             return;  // the fused kernel keeps its paths in registers
         }
         size_t const per_pass = (size_t) ((width + 7u) / 8u) * ((height + 7u) / 8u) * 64u;
-        if (per_pass > kWavefrontMaxPaths) {
+        if (per_pass > batch_cap()) {
             throw std::runtime_error("reserve: one pass of that rectangle exceeds one batch");
         }
         // (the batches launch_wavefront would cut such a call into)
-        size_t const most = std::max<size_t>(1, kWavefrontMaxPaths / per_pass);
+        device_scope const on_device(r->device);
+        size_t const most = std::max<size_t>(1, batch_limit(*r, per_pass) / per_pass);
         uint32_t batches = (uint32_t) ((pass_count + most - 1u) / most);
         if (pass_count >= 2u && per_pass * pass_count >= kSplitMinPaths) {
             batches = std::max(batches, 2u);
         }
         size_t const batch = (pass_count + batches - 1u) / batches;
-        device_scope const on_device(r->device);
         bool const binned = r->binning != RT_HIP_BINNING_OFF;  // decided later: be ready for it
         ensure_wavefront(*r, 0, per_pass * batch, r->cfg.max_depth + 1u, binned);
         if (batches >= 2u) {

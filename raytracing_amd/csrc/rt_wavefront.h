@@ -72,6 +72,7 @@ enum : uint32_t {
     kStatWords = 16,
 };
 constexpr uint32_t kScanThreads = 1024;
+constexpr uint32_t kScanTilesPerThread = 4;  // of the one-workgroup scan over the tile sums
 
 // Live-list entry = pid | flags.
 constexpr uint32_t kLiveHasShadow = 0x40000000u;
@@ -320,17 +321,36 @@ __global__ void __launch_bounds__(kScanThreads) wf_scan_tiles_kernel(wavefront_p
     __shared__ uint32_t scratch[3][kScanThreads];
     uint32_t const n = in_count_ptr ? *in_count_ptr : in_count;
     uint32_t const chunks = (n + 63u) / 64u;
-    uint32_t const tiles = (chunks + kTileChunks - 1u) / kTileChunks;  // <= kScanThreads
+    uint32_t const tiles = (chunks + kTileChunks - 1u) / kTileChunks;
+    // thread t takes tiles t * kScanTilesPerThread ...: their sum goes through the workgroup's
+    // scan, their own offsets follow from the thread's exclusive prefix
     uint32_t const t = threadIdx.x;
+    uint32_t const first_tile = t * kScanTilesPerThread;
+    triple own[kScanTilesPerThread];
     triple mine{0u, 0u, 0u};
-    if (t < tiles) {
-        mine = triple{p.tile_sums[3u * t], p.tile_sums[3u * t + 1u], p.tile_sums[3u * t + 2u]};
+    for (uint32_t k = 0; k < kScanTilesPerThread; ++k) {
+        uint32_t const tile = first_tile + k;
+        own[k] = triple{0u, 0u, 0u};
+        if (tile < tiles) {
+            own[k] = triple{p.tile_sums[3u * tile], p.tile_sums[3u * tile + 1u],
+                p.tile_sums[3u * tile + 2u]};
+        }
+        mine.live += own[k].live;
+        mine.closest += own[k].closest;
+        mine.shadow += own[k].shadow;
     }
     triple const incl = block_inclusive_scan<kScanThreads>(mine, scratch);
-    if (t < tiles) {
-        p.tile_sums[3u * t + 0u] = incl.live - mine.live;  // exclusive: the tile's offsets
-        p.tile_sums[3u * t + 1u] = incl.closest - mine.closest;
-        p.tile_sums[3u * t + 2u] = incl.shadow - mine.shadow;
+    triple run{incl.live - mine.live, incl.closest - mine.closest, incl.shadow - mine.shadow};
+    for (uint32_t k = 0; k < kScanTilesPerThread; ++k) {
+        uint32_t const tile = first_tile + k;
+        if (tile < tiles) {
+            p.tile_sums[3u * tile + 0u] = run.live;  // exclusive: the tile's offsets
+            p.tile_sums[3u * tile + 1u] = run.closest;
+            p.tile_sums[3u * tile + 2u] = run.shadow;
+        }
+        run.live += own[k].live;
+        run.closest += own[k].closest;
+        run.shadow += own[k].shadow;
     }
     if (t == kScanThreads - 1u) {
         uint32_t* const ctl = p.control + trip * kCtlWords;

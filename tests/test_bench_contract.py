@@ -36,9 +36,9 @@ def test_synthetic_4k_defaults(monkeypatch):
     import bench
     args = bench.parse_args()
     assert (args.width, args.height, args.max_depth) == (3840, 2160, 7)
-    # a step is two batches of the pipeline, each of at most 2^26 paths
+    # a step is two batches of the pipeline, each of at most 2^28 paths
     assert args.spp_per_step % 2 == 0
-    assert args.width * args.height * (args.spp_per_step // 2) <= 1 << 26
+    assert args.width * args.height * (args.spp_per_step // 2) <= 1 << 28
 
 
 def test_cpu_threads_respects_the_jobs_share(monkeypatch):

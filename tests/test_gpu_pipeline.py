@@ -296,29 +296,58 @@ def test_trip_counts_and_kernel_times(hyperion):
         r.close()
 
 
-def test_one_pass_larger_than_a_batch_is_refused(cornell):
-    """8192 x 8256 pixels = 67.6 M paths per pass, more than the 2^26 one batch holds: the
-    pipeline must refuse the call (it used to truncate its lists silently); the fused kernel,
-    which keeps no lists, still renders it, and so does the pipeline in two halves."""
-    w, h, tile = 8192, 8256, (1024, 1032)
+def test_one_pass_larger_than_a_batch_is_refused(cornell, monkeypatch):
+    """A batch holds at most 2^28 paths, or what RT_HIP_MAX_BATCH_PATHS allows: here 2^22, and
+    2048 x 2064 pixels = 4.2 M paths per pass.  The pipeline must refuse the call (it used to
+    truncate its lists silently); the fused kernel, which keeps no lists, still renders it, and
+    so does the pipeline in two halves - or in one piece once the bound is lifted."""
+    w, h, tile = 2048, 2064, (256, 258)
+    monkeypatch.setenv("RT_HIP_MAX_BATCH_PATHS", str(1 << 22))
     r = hip.HipRenderer(w, h, 1, tile, accel=hip.ACCEL_REBUILT)
     try:
         r.upload_scene(cornell.desc)
         r.upload_seeds(host.seed_schedule(0, 1, r.tile_count))
         cam = cornell.camera(w, h)
         r.clear()
-        with pytest.raises(RuntimeError, match="more than the 67108864"):
+        with pytest.raises(RuntimeError, match="more than the 4194304"):
             r.render(cam, 0, 1)
         with pytest.raises(RuntimeError, match="exceeds one batch"):
             r.reserve(w, h, 1)
         r.render(cam, 0, 1, rect=(0, 0, w, h // 2))
         r.render(cam, 0, 1, rect=(0, h // 2, w, h))
         halves, _ = r.read_accum()
+        monkeypatch.delenv("RT_HIP_MAX_BATCH_PATHS")
+        r.clear()
+        r.render(cam, 0, 1)
+        whole, _ = r.read_accum()
     finally:
         r.close()
-    # (an edge-on light sample makes the shader itself produce NaN: a few pixels in 67 M)
+    assert np.array_equal(np.nan_to_num(halves), np.nan_to_num(whole))
+    # (an edge-on light sample makes the shader itself produce NaN: a few pixels in 4 M)
     assert np.isnan(halves).any(axis=2).mean() < 1e-5 and np.nanmax(halves[..., :3]) > 0
     assert (np.nan_to_num(halves[::517, ::511, :3]).sum(axis=2) > 0).mean() > 0.5
+
+
+def test_batches_larger_than_one_scan_pass(cornell):
+    """160 passes of 1280 x 720 in one call are two batches of 73.7 M paths: more than 2^26, so
+    the one-workgroup scan over the compaction's tile sums takes several tiles per thread.  The
+    image must be the one that calls of 40 passes (batches of 18 M paths) give, bit for bit."""
+    w, h, md, tile, spp = 1280, 720, 2, (160, 90), 160
+    images = []
+    for per_call in (spp, 40):
+        r = hip.HipRenderer(w, h, md, tile, accel=hip.ACCEL_REBUILT)
+        try:
+            r.upload_scene(cornell.desc)
+            r.upload_seeds(host.seed_schedule(0, spp, r.tile_count))
+            cam = cornell.camera(w, h)
+            r.clear()
+            for first in range(0, spp, per_call):
+                r.render(cam, first, per_call)
+            images.append(r.read_accum()[0])
+        finally:
+            r.close()
+    assert np.array_equal(np.nan_to_num(images[0]), np.nan_to_num(images[1]))
+    assert np.nanmax(images[0][..., :3]) > 0
 
 
 def test_reserve_then_render(cornell):

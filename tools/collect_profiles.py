@@ -10,10 +10,10 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 SETS = {  # letter -> bench workload
-    "h": dict(scene="hyperion_rect_light", width=1280, height=720, spp_per_step=128),
-    "k": dict(scene="synthetic_4k", width=3840, height=2160, spp_per_step=16),
-    "s": dict(scene="staircase_reduced", width=1280, height=720, spp_per_step=128),
-    "m": dict(scene="mustang_red_reduced", width=1280, height=720, spp_per_step=128),
+    "h": dict(scene="hyperion_rect_light", width=1280, height=720, spp_per_step=512),
+    "k": dict(scene="synthetic_4k", width=3840, height=2160, spp_per_step=64),
+    "s": dict(scene="staircase_reduced", width=1280, height=720, spp_per_step=512),
+    "m": dict(scene="mustang_red_reduced", width=1280, height=720, spp_per_step=512),
 }
 NOTE = ("profiles/{rnd}/{letter}_pmc.txt (tools/pmc_passes.sh: one rocprofv3 --pmc pass per counter "
         "group over `bench.py --steps 2 --warmup 1 --no-work-counters`, i.e. 6 render calls, the "
