@@ -1142,17 +1142,25 @@ size_t batch_cap() {
     return cap;
 }
 
-// Most paths one batch may hold right now: batch_cap(), or less when the device is short of
-// memory - both state sets together (two batches in flight) stay within half of what is free,
-// counting what the renderer holds already as free.  One pass of the rectangle is the smallest
-// batch there is, so up to the cap `per_pass` is always allowed (its allocation then succeeds or
-// fails as such); a pass beyond the cap gets the cap, and the caller refuses it.
-size_t batch_limit(rt_hip_renderer const& r, size_t per_pass) {
+// Most paths one batch of a call of `pass_count` passes may hold right now: batch_cap(), or less
+// when the device is short of memory - both state sets together (two batches in flight) stay
+// within half of what is free, counting what the renderer holds already as free.  One pass of
+// the rectangle is the smallest batch there is, so up to the cap `per_pass` is always allowed
+// (its allocation then succeeds or fails as such); a pass beyond the cap gets the cap, and the
+// caller refuses it.  The device is asked only when the call's batches would make the state
+// arrays grow.
+size_t batch_limit(rt_hip_renderer const& r, size_t per_pass, uint32_t pass_count) {
     size_t const cap = batch_cap();
-    size_t free_bytes = 0, total_bytes = 0;
     if (per_pass >= cap) {
         return cap;
     }
+    // (two batches at least once the call is large enough to be split, see launch_wavefront)
+    bool const split = pass_count >= 2u && per_pass * pass_count >= kSplitMinPaths;
+    size_t const wanted = std::min(cap, per_pass * (split ? (pass_count + 1u) / 2u : pass_count));
+    if (wanted <= (split ? std::min(r.wf_paths[0], r.wf_paths[1]) : r.wf_paths[0])) {
+        return cap;
+    }
+    size_t free_bytes = 0, total_bytes = 0;
     if (hipMemGetInfo(&free_bytes, &total_bytes) != hipSuccess) {
         (void) hipGetLastError();
         return cap;
@@ -1176,7 +1184,7 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     static_assert(kWavefrontMaxPaths / 64u / kTileChunks <= kScanThreads * kScanTilesPerThread,
         "one workgroup must be able to scan the tile sums");
     static_assert(kWavefrontMaxPaths <= (size_t) kLivePidMask + 1u, "a pid must fit a list entry");
-    size_t const limit = fixed ? fixed_paths : batch_limit(r, per_pass);
+    size_t const limit = fixed ? fixed_paths : batch_limit(r, per_pass, p.pass_count);
     if (per_pass > limit) {
         // one pass of the rectangle is the smallest batch; the compaction (one workgroup scans
         // the tile sums) and the state arrays are sized for `limit` paths
@@ -2184,7 +2192,7 @@ int rt_hip_reserve(rt_hip_renderer* r, uint32_t width, uint32_t height, uint32_t
         }
         // (the batches launch_wavefront would cut such a call into)
         device_scope const on_device(r->device);
-        size_t const most = std::max<size_t>(1, batch_limit(*r, per_pass) / per_pass);
+        size_t const most = std::max<size_t>(1, batch_limit(*r, per_pass, pass_count) / per_pass);
         uint32_t batches = (uint32_t) ((pass_count + most - 1u) / most);
         if (pass_count >= 2u && per_pass * pass_count >= kSplitMinPaths) {
             batches = std::max(batches, 2u);
