@@ -202,9 +202,11 @@ RT_DEV bool pid_pixel(wavefront_params const& p, uint32_t pid, uint32_t& x, uint
 }
 
 // Start of path `pid`: its pixel, its seed after the two jitter draws and its primary ray
-// (megakernel_raytracer.comp:85-100).  Trip 0 has no stored state: the trace launch and the
-// shade launch both derive the primary ray from the pid (same arithmetic, same bits), which
-// is cheaper than writing it to memory and reading it back twice.
+// (megakernel_raytracer.comp:85-100).  Trip 0 has no stored rays: the trace launch derives the
+// primary ray from the pid and leaves its direction and the seed in ray_d[pid] for the shading
+// launch (16 bytes written and read per path against some 250 instructions of a launch that is
+// bound by instruction issue: hyperion +4 %, teapot stand-in +2.6 %); the settle launch, which
+// waits for memory and needs the ray of one path in seven, derives it again.
 RT_DEV bool primary_of_pid(wavefront_params const& p, uint32_t pid, uint32_t& seed, f3& origin,
     f3& direction) {
     uint32_t x, y, pass;
@@ -741,7 +743,11 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 if (FIRST) {
                     uint32_t seed;
                     pid = i;
-                    return primary_of_pid(p, pid, seed, o, d);
+                    bool const inside = primary_of_pid(p, pid, seed, o, d);
+                    if (inside) {
+                        stream_store(&p.ray_d[pid], make_float4(d.x, d.y, d.z, __uint_as_float(seed)));
+                    }
+                    return inside;
                 }
                 pid = stream_load(&q_closest[i]);
                 float4 const ro = stream_load(&p.ray_o[pid]);
@@ -788,6 +794,8 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 if (active) {
                     o = make_float4(origin.x, origin.y, origin.z, 0.0f);
                     d = make_float4(direction.x, direction.y, direction.z, 0.0f);
+                    stream_store(&p.ray_d[pid], make_float4(direction.x, direction.y, direction.z,
+                                                    __uint_as_float(seed)));
                 }
             } else if (active) {
                 o = stream_load(&p.ray_o[pid]);
@@ -1173,6 +1181,9 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
                     g.occluded =
                         (item.y & kLiveHasShadow) != 0u ? stream_load(&p.occluded[pid]) : 0u;
                 }
+                if (FIRST) {
+                    g.thr = stream_load(&p.ray_d[pid]);  // primary direction, w = seed bits
+                }
                 g.h0 = stream_load(&p.hit0[pid]);
                 g.h1 = stream_load(&p.hit1[pid]);
             }
@@ -1206,7 +1217,11 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
                 pair_result pr;
                 pr.hit = true;
                 if (FIRST) {
-                    primary_of_pid(p, pid, ps.seed, rp.origin, rp.direction);
+                    // the trace launch left the primary ray's direction and the seed after the
+                    // two jitter draws where the closest-hit ray's direction lives
+                    rp.origin = load3(p.cam.position);
+                    rp.direction = mk3(cur.thr.x, cur.thr.y, cur.thr.z);
+                    ps.seed = __float_as_uint(cur.thr.w);
                     ps.radiance = splat3(0.0f);
                     ps.throughput = splat3(1.0f);
                     ps.nee = splat3(0.0f);
