@@ -133,8 +133,20 @@ struct slab_ray {
 // whenever the planes lie on different sides of zero, and the box is lost although the ray runs
 // inside the slab.  With 1e18 both distances are finite and of opposite sign (inside the slab:
 // no constraint) or of the same sign and far beyond any scene (outside: a miss).
+#ifndef RT_SLAB_FAST_RCP
+#define RT_SLAB_FAST_RCP 1
+#endif
 RT_DEV float slab_reciprocal(float d) {
+#if RT_SLAB_FAST_RCP
+    // the hardware reciprocal (1 ulp) instead of a correctly rounded division: the box test is
+    // conservative and its margin (slab_box) covers the extra half ulp, which scales the near
+    // and the far distance of an axis alike.  Zero and denormal components give infinity there
+    // and the huge finite value here.
+    float const r = __builtin_amdgcn_rcpf(d);
+    return fabsf(r) <= 1.0e18f ? r : copysignf(1.0e18f, d);
+#else
     return d == 0.0f ? copysignf(1.0e18f, d) : 1.0f / d;
+#endif
 }
 
 RT_DEV slab_ray make_slab_ray(f3 o, f3 d) {
@@ -161,10 +173,10 @@ RT_DEV void slab_box(slab_ray const& r, float near_x, float near_y, float near_z
     float const fy = __builtin_fmaf(far_y, r.inv.y, r.oinv.y);
     float const nz = __builtin_fmaf(near_z, r.inv.z, r.oinv.z);
     float const fz = __builtin_fmaf(far_z, r.inv.z, r.oinv.z);
-    // widened by 4 ulp in all (rounding may add candidates, never lose the true hit); the whole
+    // widened by 6 ulp in all (rounding may add candidates, never lose the true hit); the whole
     // margin sits on the exit side, so the entry distance is also the children's sort key as is
     t_enter = fmaxf(fmaxf(nx, ny), fmaxf(nz, 0.0f));
-    t_exit = fminf(fminf(fx, fy), fminf(fz, t_max)) * 1.0000005f;
+    t_exit = fminf(fminf(fx, fy), fminf(fz, t_max)) * 1.0000007f;
 }
 
 // Where in a wide node the near and the far planes of each axis lie for this ray, as byte
