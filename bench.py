@@ -6,7 +6,7 @@
 One step = one rt_hip_render call over the whole frame at max_depth 7, tracing --spp-per-step
 passes of every pixel (scene, seeds and accumulator already resident in HBM; default 512 passes,
 which the library traces as two batches of 256 side by side on two streams: 2 x 236 M paths,
-78 GB of path state of the 288 GB).  The reported
+76 GB of path state of the 288 GB).  The reported
 value is pixel-samples per second over all GPUs, in Msamples/s; Mrays/s comes from the device
 ray counters of the same timed region.
 
@@ -51,18 +51,18 @@ NODE_BYTES = 112        # one wide node = boxes of four children (96 B) + four c
 TRI_BYTES = 36          # nine position floats per triangle test
 INSTANCE_BYTES = 64     # one instance record per TLAS leaf entered (reported, not in `achieved`)
 # per-ray state the trace launch streams: pid 4 + ray 32 in, hit record 24 out (closest) /
-# pid 4 + ray 32 in, flag 4 out (occlusion) -- reported, not in `achieved`
+# pid 4 + ray 32 + radiance 16 + pending light sample 16 in, radiance 16 out for the rays that
+# get through, about half (occlusion) -- reported, not in `achieved`
 CLOSEST_STATE_BYTES = 60
-SHADOW_STATE_BYTES = 40
+SHADOW_STATE_BYTES = 76
 # path state the two shading launches stream (rt_wavefront.h): a live-list entry, the hit
 # record's first quad and the raw slot for every live path; for a path that goes on, also
-# radiance, throughput, pending light sample, ray origin and direction, the rest of the hit
-# record and the occlusion flag in, and radiance, throughput, light sample, two rays and the
-# raw slot out
+# radiance, throughput, ray origin and direction and the rest of the hit record in, and radiance,
+# throughput, light sample, two rays and the raw slot out
 SHADE_LIVE_BYTES = 4 + 16 + 4
-SHADE_GOING_READ_BYTES = 8 + 5 * 16 + 8 + 4
+SHADE_GOING_READ_BYTES = 8 + 4 * 16 + 8
 SHADE_GOING_WRITE_BYTES = 7 * 16 + 4
-PATH_STATE_BYTES = 140
+PATH_STATE_BYTES = 136
 # the previous definition, on the REFERENCE's binary tree (kept under its own key):
 REF_NODE_BYTES = 32
 REF_TRI_BYTES = 36
@@ -88,9 +88,9 @@ def parse_args(argv=None):
     ap.add_argument("--height", type=int, default=None)
     ap.add_argument("--max-depth", type=int, default=7)
     ap.add_argument("--spp-per-step", type=int, default=None,
-                    help="passes per render call (default 128 = two batches of 64 passes in "
-                         "flight side by side: 2 x 59 M paths, 16.5 GB of path state at 1280x720; "
-                         "64 per call is 9 %% slower per sample, 16 per call 30 %%)")
+                    help="passes per render call (default 512 = two batches of 256 passes in "
+                         "flight side by side: 2 x 236 M paths, 76 GB of path state at 1280x720; "
+                         "128 per call is 7 %% slower per sample, 64 per call 18 %%)")
     ap.add_argument("--total-spp", type=int, default=None,
                     help="strong scaling: one step = this many passes of the frame in all, "
                          "shared by the ranks (pass_range); default: --spp-per-step passes per "

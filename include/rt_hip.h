@@ -153,7 +153,7 @@ int rt_hip_render(rt_hip_renderer* r, const rt_camera* camera, uint32_t first_pa
 /* Optional: allocates now what rt_hip_render would otherwise allocate on its first call (and
  * grow, with a device synchronisation, whenever a larger call arrives): the pipeline's path
  * state for calls of up to pass_count passes over rectangles of up to width x height pixels
- * (164 B per path in flight, at most 2^28 paths per batch - less when the device is short of
+ * (160 B per path in flight, at most 2^28 paths per batch - less when the device is short of
  * memory or the environment variable RT_HIP_MAX_BATCH_PATHS says so -, two batches - two sets
  * of state - when the call is large enough to be traced as two, see rt_hip_render; plus the ray-binning
  * buffers unless binning is forced off).  After it, render calls within that size allocate nothing.  No counterpart in

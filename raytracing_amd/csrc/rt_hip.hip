@@ -865,8 +865,8 @@ void launch_path_trace(rt_hip_renderer& r, render_params& p, hipStream_t stream)
     }
 }
 
-// Paths in flight per batch of the wavefront pipeline: at most 2^28 (164 B of state, lists and
-// counters per path, 176 B with the ray binning's buffers: 44-47 GB per state set, two sets for
+// Paths in flight per batch of the wavefront pipeline: at most 2^28 (160 B of state, lists and
+// counters per path, 172 B with the ray binning's buffers: 43-46 GB per state set, two sets for
 // two batches in flight, of 288 GB).  Large batches amortise launch tails and give the late,
 // sparse bounces launches worth starting: per sample, 1280x720 renders 1.15x faster at 64 passes
 // per batch than at 16, and 1.04x / 1.10x faster again at 128 / 256 (two batches in flight each
@@ -1059,7 +1059,7 @@ constexpr size_t kSplitMinPaths = (size_t) 1 << 24;
 void take_state_arrays(wavefront_params& w, wavefront_params const& set) {
     w.ray_o = set.ray_o, w.ray_d = set.ray_d, w.sh_o = set.sh_o, w.sh_d = set.sh_d;
     w.nee = set.nee, w.thr = set.thr, w.rad = set.rad, w.hit0 = set.hit0, w.hit1 = set.hit1;
-    w.occluded = set.occluded, w.live = set.live, w.q_closest = set.q_closest;
+    w.live = set.live, w.q_closest = set.q_closest;
     w.q_shadow = set.q_shadow, w.raw = set.raw, w.going = set.going;
     w.going_count = set.going_count, w.chunk_counts = set.chunk_counts;
     w.tile_sums = set.tile_sums, w.control = set.control;
@@ -1109,7 +1109,6 @@ void ensure_wavefront(rt_hip_renderer& r, int set, size_t paths, uint32_t trips,
     w.rad = (float4*) alloc(paths * 16);
     w.hit0 = (float4*) alloc(paths * 16);
     w.hit1 = (float2*) alloc(paths * 8);
-    w.occluded = (uint32_t*) alloc(paths * 4);
     w.live = (uint32_t*) alloc(paths * 4);
     w.q_closest = (uint32_t*) alloc(paths * 4);
     w.q_shadow = (uint32_t*) alloc(paths * 4);
@@ -1585,7 +1584,7 @@ constexpr size_t kScratchTileSums =
 constexpr size_t kScratchControl = scratch_align((size_t) (kNoAllocTrips + 1u) * kCtlWords * 4u);
 constexpr size_t kScratchGoingCount =
     scratch_align(((kNoAllocPaths + kRegionSlots - 1u) / kRegionSlots) * 4u);
-constexpr size_t kScratchBytes = 8u * kScratchVec4 + 2u * kScratchVec2 + 5u * kScratchWord +
+constexpr size_t kScratchBytes = 8u * kScratchVec4 + 2u * kScratchVec2 + 4u * kScratchWord +
                                  kScratchGoingCount + kScratchChunkCounts + kScratchTileSums +
                                  kScratchControl;
 static_assert(kScratchBytes <= (size_t) 48u << 20, "keep the resident scratch array modest");
@@ -1631,7 +1630,6 @@ wavefront_params carve_scratch(unsigned char* base, unsigned long long* wave_sta
     w.rad = (float4*) take(kScratchVec4);
     w.hit0 = (float4*) take(kScratchVec4);
     w.hit1 = (float2*) take(kScratchVec2);
-    w.occluded = (uint32_t*) take(kScratchWord);
     w.live = (uint32_t*) take(kScratchWord);
     w.q_closest = (uint32_t*) take(kScratchWord);
     w.q_shadow = (uint32_t*) take(kScratchWord);

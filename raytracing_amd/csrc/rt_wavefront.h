@@ -92,7 +92,6 @@ struct wavefront_params {
     float4* rad;       // radiance so far (final when the path is over), w = depth bits
     float4* hit0;      // instance bits, triangle bits, b0, b1   (instance = RT_HIP_MISS: no hit)
     float2* hit1;      // b2, t
-    uint32_t* occluded;  // outcome of the occlusion ray
     uint32_t* live;          // compacted: pid | flags of every path with a ray this trip
     uint32_t* q_closest;     // compacted pids with a closest-hit ray
     uint32_t* q_shadow;      // compacted pids with an occlusion ray
@@ -199,6 +198,21 @@ RT_DEV bool pid_pixel(wavefront_params const& p, uint32_t pid, uint32_t& x, uint
     x = p.x0 + (block % p.blocks_x) * 8u + (lane & 7u);
     y = p.y0 + (block / p.blocks_x) * 8u + (lane >> 3);
     return x < p.x1 && y < p.y1;
+}
+
+// An occlusion ray that got through: its path's pending light sample becomes radiance
+// (megakernel_raytracer.comp:547-549).  The trace launch does this itself, for the rays it finds
+// unoccluded, instead of leaving a flag for the launches after it: those walk every live path
+// and are bound by the memory they move, while the trace launch is bound by instruction issue
+// and has the bandwidth to spare.  Nothing else touches rad[pid] between the shading launch
+// that stored the sample and the one that would have added it, so the sum is the same.
+// `rad` and `nee` are the path's rad[pid] and nee[pid], fetched together with the ray so that
+// nothing waits for them here.
+RT_DEV void add_light_sample(wavefront_params const& p, uint32_t pid, float4 rad, float4 nee) {
+    rad.x = rad.x + nee.x;
+    rad.y = rad.y + nee.y;
+    rad.z = rad.z + nee.z;
+    stream_store(&p.rad[pid], rad);
 }
 
 // Start of path `pid`: its pixel, its seed after the two jitter draws and its primary ray
@@ -762,19 +776,24 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                         __uint_as_float(wk.best.triangle), wk.best.b0, wk.best.b1));
                 stream_store(&p.hit1[pid], make_float2(wk.best.b2, wk.best.t));
             });
+        float4 lane_rad = make_float4(0.0f, 0.0f, 0.0f, 0.0f), lane_nee = lane_rad;
         run(fast_walk<true, COUNT, true>{}, n_shadow,
             p.control + trip * kCtlWords + kCtlShadowCursor,
             [&](uint32_t i, uint32_t& pid, f3& o, f3& d, float& t_limit) {
                 pid = stream_load(&q_shadow[i]);
                 float4 const ro = stream_load(&p.sh_o[pid]);
                 float4 const rd = stream_load(&p.sh_d[pid]);
+                lane_rad = stream_load(&p.rad[pid]);
+                lane_nee = stream_load(&p.nee[pid]);
                 o = mk3(ro.x, ro.y, ro.z);
                 d = mk3(rd.x, rd.y, rd.z);
                 t_limit = ro.w;
                 return true;
             },
             [&](uint32_t pid, fast_walk<true, COUNT, true> const& wk) {
-                stream_store(&p.occluded[pid], wk.found ? 1u : 0u);
+                if (!wk.found) {
+                    add_light_sample(p, pid, lane_rad, lane_nee);
+                }
             });
     } else
 #endif
@@ -825,9 +844,12 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
             bool const active = i < n_shadow;
             uint32_t const pid = active ? stream_load(&q_shadow[i]) : 0u;
             float4 o = make_float4(0.0f, 0.0f, 0.0f, 1.0f), d = make_float4(1.0f, 0.0f, 0.0f, 0.0f);
+            float4 rad = d, nee = d;
             if (active) {
                 o = stream_load(&p.sh_o[pid]);
                 d = stream_load(&p.sh_d[pid]);
+                rad = stream_load(&p.rad[pid]);
+                nee = stream_load(&p.nee[pid]);
             }
             hit_result unused;
             bool blocked;
@@ -838,8 +860,8 @@ __global__ void __launch_bounds__(ACCEL == RT_HIP_ACCEL_REBUILT ? kExtendThreads
                 blocked = active && trace_ref<true, COUNT>(p.sc, mk3(o.x, o.y, o.z),
                                         mk3(d.x, d.y, d.z), o.w, unused, cnt);
             }
-            if (active) {
-                stream_store(&p.occluded[pid], blocked ? 1u : 0u);
+            if (active && !blocked) {
+                add_light_sample(p, pid, rad, nee);
             }
         }
     }
@@ -1013,14 +1035,13 @@ __global__ void __launch_bounds__(kSettleThreads, RT_SETTLE_GROUPS_PER_CU * 4)
             // The path ends at this trip; its radiance becomes final.  Only what the case at
             // hand reads is fetched: the waves here are many and wait for memory, not for the
             // VALU, so a dependent load costs less than the bytes of an unconditional one.
-            bool const has_shadow = !FIRST && (entry & kLiveHasShadow) != 0u;
-            bool const lit = has_shadow && stream_load(&p.occluded[pid]) == 0u;
+            // (the outcome of its occlusion ray is in rad[pid] already: add_light_sample)
             bool const sky = traced && !hit && feat<F>(kFeatSky) && sc.sky_light >= 0;
-            if (!FIRST && !lit && !sky && !hit) {
+            if (!FIRST && !sky && !hit) {
                 continue;  // nothing is added: rad[pid] is final as it stands
             }
             ray_pair rp;
-            rp.has_shadow = has_shadow;
+            rp.has_shadow = false;
             rp.has_closest = traced;
             rp.origin = rp.direction = splat3(0.0f);
             path_state ps;
@@ -1031,7 +1052,7 @@ __global__ void __launch_bounds__(kSettleThreads, RT_SETTLE_GROUPS_PER_CU * 4)
             ps.depth = trip;
             ps.seed = 0u;
             pair_result pr;
-            pr.occluded = !lit;
+            pr.occluded = false;
             pr.hit = hit;
             if (FIRST) {
                 if (sky || hit) {
@@ -1040,10 +1061,8 @@ __global__ void __launch_bounds__(kSettleThreads, RT_SETTLE_GROUPS_PER_CU * 4)
             } else {
                 float4 const rad = stream_load(&p.rad[pid]);
                 ps.radiance = mk3(rad.x, rad.y, rad.z);
-                if (lit || sky) {
-                    float4 const nee = stream_load(&p.nee[pid]);
-                    ps.nee = mk3(nee.x, nee.y, nee.z);
-                    ps.last_bsdf_pdf = nee.w;
+                if (sky) {
+                    ps.last_bsdf_pdf = stream_load(&p.nee[pid]).w;
                 }
                 if (sky || hit) {
                     float4 const thr = stream_load(&p.thr[pid]);
@@ -1091,10 +1110,9 @@ __global__ void __launch_bounds__(kSettleThreads, RT_SETTLE_GROUPS_PER_CU * 4)
 
 // What wf_shade_kernel holds of a going path before it shades it.
 struct going_state {
-    float4 rad, thr, nee, h0;
+    float4 rad, thr, h0;
     f3 o, d;
     float2 h1;
-    uint32_t occluded;
 };
 
 template <bool FIRST, uint32_t F>
@@ -1175,11 +1193,8 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
                 if (!FIRST) {
                     g.rad = stream_load(&p.rad[pid]);
                     g.thr = stream_load(&p.thr[pid]);
-                    g.nee = stream_load(&p.nee[pid]);
                     g.o = stream_load3(&p.ray_o[pid]);
                     g.d = stream_load3(&p.ray_d[pid]);
-                    g.occluded =
-                        (item.y & kLiveHasShadow) != 0u ? stream_load(&p.occluded[pid]) : 0u;
                 }
                 if (FIRST) {
                     g.thr = stream_load(&p.ray_d[pid]);  // primary direction, w = seed bits
@@ -1209,7 +1224,7 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
             uint32_t const entry = item.y;
             uint32_t const pid = entry & kLivePidMask;
             ray_pair rp;
-            rp.has_shadow = (entry & kLiveHasShadow) != 0u;
+            rp.has_shadow = false;  // (the one of the bounce before is settled: add_light_sample)
             rp.has_closest = active;
             uint32_t closest_hits = 0, shadow_skipped = 0;
             path_state ps;
@@ -1229,13 +1244,15 @@ __global__ void __launch_bounds__(kShadeThreads, RT_SHADE_WAVES_PER_SIMD)
                     ps.depth = 0;
                     pr.occluded = false;
                 } else {
-                    pr.occluded = rp.has_shadow && cur.occluded != 0u;
+                    pr.occluded = false;
                     ps.radiance = mk3(cur.rad.x, cur.rad.y, cur.rad.z);
                     ps.depth = __float_as_uint(cur.rad.w);
                     ps.throughput = mk3(cur.thr.x, cur.thr.y, cur.thr.z);
                     ps.seed = __float_as_uint(cur.thr.w);
-                    ps.nee = mk3(cur.nee.x, cur.nee.y, cur.nee.z);
-                    ps.last_bsdf_pdf = cur.nee.w;
+                    // (both are written before they are read: a path that goes on draws a new
+                    // light sample or has none, and its BSDF sample sets the pdf)
+                    ps.nee = splat3(0.0f);
+                    ps.last_bsdf_pdf = 0.0f;
                     rp.origin = cur.o;
                     rp.direction = cur.d;
                 }
