@@ -1055,6 +1055,40 @@ void init_launch_plan(rt_hip_renderer& r) {
 // faster than as one batch although the halves' launches are smaller.
 constexpr size_t kSplitMinPaths = (size_t) 1 << 24;
 
+// The multiplier and shift that divide() turns into floor(n / d) for n < 2^31 (rt_wavefront.h),
+// checked against the division itself at the ends of the range and around multiples of d.
+divider make_divider(uint32_t d) {
+    if (d == 0u) {
+        throw std::runtime_error("make_divider: zero");
+    }
+    uint32_t shift = 0;
+    while ((2u << shift) <= d && shift < 31u) {
+        ++shift;  // floor(log2 d)
+    }
+    divider v{};
+    v.shift = shift;
+    if ((d & (d - 1u)) == 0u) {
+        v.mul = 0u, v.keep = ~0u;
+    } else {
+        unsigned long long const two_k = 1ull << (32u + shift);
+        v.mul = (uint32_t) ((two_k + d - 1u) / d);
+        v.keep = 0u;
+    }
+    auto quotient = [&](uint32_t n) {
+        return (uint32_t) ((((unsigned long long) n * v.mul) >> 32) + (n & v.keep)) >> v.shift;
+    };
+    uint32_t const top = 0x7FFFFFFFu;
+    uint32_t const probes[] = {0u, 1u, d - 1u, d, d + 1u, 2u * d - 1u, 2u * d, top, top - 1u,
+        top / d * d, top / d * d - 1u, (top / 2u) / d * d, (top / 2u) / d * d - 1u, 0x0FFFFFFFu};
+    for (uint32_t n : probes) {
+        if (n <= top && quotient(n) != n / d) {
+            throw std::logic_error("make_divider: wrong quotient for " + std::to_string(n) + " / " +
+                                   std::to_string(d));
+        }
+    }
+    return v;
+}
+
 // Points `w` at the state arrays, lists and counters of `set`.
 void take_state_arrays(wavefront_params& w, wavefront_params const& set) {
     w.ray_o = set.ray_o, w.ray_d = set.ray_d, w.sh_o = set.sh_o, w.sh_d = set.sh_d;
@@ -1333,6 +1367,10 @@ void launch_wavefront(rt_hip_renderer& r, render_params const& p, hipStream_t st
     w.tile_height = p.tile_height;
     w.tiles_x = p.tiles_x;
     w.tile_count = p.tile_count;
+    w.by_per_pass = make_divider(w.block_count * 64u);
+    w.by_blocks_x = make_divider(w.blocks_x);
+    w.by_tile_width = make_divider(w.tile_width);
+    w.by_tile_height = make_divider(w.tile_height);
     w.max_depth = p.max_depth;
     w.preview = p.preview;
     w.counters = p.counters;

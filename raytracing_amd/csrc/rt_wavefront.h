@@ -79,6 +79,17 @@ constexpr uint32_t kLiveHasShadow = 0x40000000u;
 constexpr uint32_t kLiveHasClosest = 0x80000000u;
 constexpr uint32_t kLivePidMask = 0x3FFFFFFFu;
 
+// n / d for a divisor fixed per launch and n < 2^31, without the two dozen instructions of a
+// 32-bit division: floor(n / d) = (mulhi(n, mul) + (n & keep)) >> shift with, for d a power of
+// two, mul = 0, keep = ~0, shift = log2 d, and otherwise mul = ceil(2^(32 + shift) / d),
+// keep = 0, shift = floor(log2 d) (make_divider checks the pair it returns).
+struct divider {
+    uint32_t mul, keep, shift;
+};
+RT_DEV uint32_t divide(uint32_t n, divider const& d) {
+    return (__umulhi(n, d.mul) + (n & d.keep)) >> d.shift;
+}
+
 struct wavefront_params {
     scene_dev sc;
     rt_camera cam;
@@ -127,6 +138,7 @@ struct wavefront_params {
     uint32_t padded;                 // the rectangle's sides are not multiples of 8: some lanes
                                      // of its 8x8 blocks have no pixel
     uint32_t tile_width, tile_height, tiles_x, tile_count;
+    divider by_per_pass, by_blocks_x, by_tile_width, by_tile_height;  // block_count * 64, ...
     uint32_t pass_count;             // passes in this batch
     uint32_t max_depth;
     uint32_t preview;
@@ -191,12 +203,13 @@ RT_DEV unsigned long long wave_sum(uint32_t v) {
 RT_DEV bool pid_pixel(wavefront_params const& p, uint32_t pid, uint32_t& x, uint32_t& y,
     uint32_t& pass) {
     uint32_t const per_pass = p.block_count * 64u;
-    pass = pid / per_pass;
+    pass = divide(pid, p.by_per_pass);
     uint32_t const in_pass = pid - pass * per_pass;
     uint32_t const block = in_pass >> 6;
     uint32_t const lane = in_pass & 63u;
-    x = p.x0 + (block % p.blocks_x) * 8u + (lane & 7u);
-    y = p.y0 + (block / p.blocks_x) * 8u + (lane >> 3);
+    uint32_t const block_y = divide(block, p.by_blocks_x);
+    x = p.x0 + (block - block_y * p.blocks_x) * 8u + (lane & 7u);
+    y = p.y0 + block_y * 8u + (lane >> 3);
     return x < p.x1 && y < p.y1;
 }
 
@@ -229,7 +242,8 @@ RT_DEV bool primary_of_pid(wavefront_params const& p, uint32_t pid, uint32_t& se
     }
     uint32_t random_seed = p.scalar_seed;
     if (p.seeds != nullptr) {
-        uint32_t const tile = (y / p.tile_height) * p.tiles_x + x / p.tile_width;
+        uint32_t const tile =
+            divide(y, p.by_tile_height) * p.tiles_x + divide(x, p.by_tile_width);
         random_seed = p.seeds[(size_t) pass * p.tile_count + tile];
     }
     f3 const du = load3(p.cam.pixel_delta_u);
