@@ -558,7 +558,12 @@ void mesh_primitives(rt_scene_desc const& sc, rt_mesh const& mesh, bool keep_deg
     // RT_HIP_PRESPLIT: tuning knob - 0 disables, another number replaces kPresplitAboveMedian
     char const* const knob = getenv("RT_HIP_PRESPLIT");
     float const above_median = knob ? (float) atof(knob) : kPresplitAboveMedian;
-    uint32_t budget = above_median > 0.0f ? listed >> kPresplitBudgetShift : 0u;
+    // RT_HIP_PRESPLIT_BUDGET: tuning knob - extra references allowed, as a fraction of the triangles
+    char const* const budget_knob = getenv("RT_HIP_PRESPLIT_BUDGET");
+    uint32_t budget = above_median > 0.0f
+                          ? (budget_knob ? (uint32_t) ((double) listed * atof(budget_knob))
+                                         : listed >> kPresplitBudgetShift)
+                          : 0u;
     if (budget > 0u && listed >= 8u) {
         std::nth_element(areas.begin(), areas.begin() + areas.size() / 2, areas.end());
         float const large = above_median * areas[areas.size() / 2];
